@@ -1,0 +1,232 @@
+"""Generate golden vectors under tests/golden/ from the REFERENCE's own models.py.
+
+Runs only in the build container (needs /root/reference).  Never runs on the GPU box; the
+fixtures it writes are data (inputs, weights, expected outputs) and are committed.
+
+What is imported from the reference: `models.Generator_PG`, `models.Discriminator_PG`
+(/root/reference/models.py:272-616) -- it imports as-is (torch, numpy, configs only).
+`loss_functions.py` is NOT imported: its `utils` import needs parse/torchvision/cv2, which are
+not installed.  The three loss forwards (loss_functions.py:14-47, 59-74, 157-180) and the inner
+loop (train.py:357-385) are therefore replayed by `ref_step` below over the imported reference
+modules; `check_survey_pins` verifies that this replay reproduces the first-step values that
+SURVEY.md 8(c) recorded from the reference's real loss modules (same seeds, same RNG order).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--full]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import models  # noqa: the reference's models.py
+    from configs import config  # noqa
+    return models, config
+
+
+def latent(b, dim):
+    z = torch.randn(b, dim).clamp(-5, 5)  # utils.py:77
+    return z / z.norm(p=2, dim=1, keepdim=True)  # utils.py:78
+
+
+def ref_losses(G, D, x, z_d, z_gp, eps, lam=10.0, drift=0.001):
+    """D_W_loss + D_grad_pen_loss over reference modules; returns tensors with graph."""
+    real_score = D(x)
+    s_real = real_score.mean()
+    fake = G(z_d).detach()
+    fake_score = D(fake)
+    s_fake = fake_score.mean()
+    d_loss = -s_real + s_fake
+    if drift > 0:
+        d_loss = d_loss + drift * torch.square(real_score).mean()
+    x_tilde = G(z_gp).detach()
+    x_hat = eps * x + (1 - eps) * x_tilde
+    x_hat.requires_grad_()
+    out = D(x_hat)
+    g = torch.autograd.grad(outputs=out.sum(), inputs=x_hat, create_graph=True)[0]
+    norms = g.norm(2, dim=(1, 2, 3))
+    gp = lam * torch.mean((norms - 1) ** 2)
+    return dict(real_score=real_score, fake=fake, fake_score=fake_score, s_real=s_real, s_fake=s_fake, d_loss=d_loss,
+                gp=gp, norms=norms, x_hat_grad=g)
+
+
+def ref_step(G, D, oG, oD, x, z_d, z_gp, eps, z_g, lam=10.0, drift=0.001, capture=None):
+    """train.py:357-385 with n_critic=1 over the reference modules."""
+    D.zero_grad()
+    L = ref_losses(G, D, x, z_d, z_gp, eps, lam, drift)
+    total = L["d_loss"] + L["gp"]
+    total.backward()
+    if capture is not None:
+        for k, p in D.named_parameters():
+            if p.grad is not None:
+                capture["Dgrad/" + k] = p.grad.detach().clone().numpy()
+    oD.step()
+    G.zero_grad()
+    D.zero_grad()
+    fake = G(z_g)
+    g_loss = -D(fake).mean()
+    g_loss.backward()
+    if capture is not None:
+        for k, p in G.named_parameters():
+            if p.grad is not None:
+                capture["Ggrad/" + k] = p.grad.detach().clone().numpy()
+        capture["fake_g"] = fake.detach().numpy()
+    oG.step()
+    return dict(D_loss=float(total.detach()), score_real=float(L["s_real"].detach()), score_fake=float(L["s_fake"].detach()),
+                GP=float(L["gp"].detach()), G_loss=float(g_loss.detach())), L
+
+
+def state_np(net, prefix):
+    return {prefix + k: v.detach().clone().numpy() for k, v in net.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------------
+# reduced-width fixtures: every weight, input and output stored
+# ------------------------------------------------------------------------------------------
+SMALL = dict(g_widths=[32, 16, 16], d_widths=[16, 16, 32], image_size_init=4, latent_dim=32)
+
+
+def small_fixture(models, name, res, alpha, warm_steps, batch=4, seed=11):
+    torch.manual_seed(seed)
+    G = models.Generator_PG(list(SMALL["g_widths"]), image_size_init=SMALL["image_size_init"], latent_dim=SMALL["latent_dim"])
+    D = models.Discriminator_PG(list(SMALL["d_widths"]), image_size_init=SMALL["image_size_init"])
+    G.to(torch.device("cpu"), torch.float32)
+    D.to(torch.device("cpu"), torch.float32)
+    if res != SMALL["image_size_init"]:
+        G.set_resolution(res, alpha)
+        D.set_resolution(res, alpha)
+    lr = 1e-4
+    if warm_steps:
+        # warm the nets so that |grad D| is O(1) instead of ~1e-2 (last hard part)
+        oG = torch.optim.Adam(G.parameters(), lr=2e-3, betas=(0.5, 0.999))
+        oD = torch.optim.Adam(D.parameters(), lr=2e-3, betas=(0.5, 0.999))
+        for _ in range(warm_steps):
+            x = torch.rand(batch, 1, res, res) * 2 - 1
+            ref_step(G, D, oG, oD, x, latent(batch, G.latent_dim), latent(batch, G.latent_dim),
+                     torch.rand(batch, 1, 1, 1), latent(batch, G.latent_dim))
+    oG = torch.optim.Adam(G.parameters(), lr=lr, betas=(0.5, 0.999))
+    oD = torch.optim.Adam(D.parameters(), lr=lr, betas=(0.5, 0.999))
+    out = {}
+    out.update(state_np(G, "G/"))
+    out.update(state_np(D, "D/"))
+    x = torch.rand(batch, 1, res, res) * 2 - 1
+    z_d, z_gp, z_g = (latent(batch, G.latent_dim) for _ in range(3))
+    eps = torch.rand(batch, 1, 1, 1)
+    out.update(real=x.numpy(), z_d=z_d.numpy(), z_gp=z_gp.numpy(), z_g=z_g.numpy(), eps=eps.numpy())
+    with torch.no_grad():
+        out["G_of_z_d"] = G(z_d).numpy()
+        out["D_of_real"] = D(x).numpy()
+    cap = {}
+    scal, L = ref_step(G, D, oG, oD, x, z_d, z_gp, eps, z_g, capture=cap)
+    out.update(cap)
+    out["D_of_fake"] = L["fake_score"].detach().numpy()
+    out["grad_norms"] = L["norms"].detach().numpy()
+    out["x_hat_grad"] = L["x_hat_grad"].detach().numpy()
+    out["scalars"] = np.array([scal[k] for k in ("D_loss", "score_real", "score_fake", "GP", "G_loss")], dtype=np.float64)
+    out.update(state_np(G, "G_after/"))
+    out.update(state_np(D, "D_after/"))
+    out["meta"] = np.array([res, alpha, SMALL["image_size_init"], SMALL["latent_dim"], batch, lr], dtype=np.float64)
+    path = os.path.join(OUT, f"small_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: scalars={out['scalars']}, norms={out['grad_norms']}")
+
+
+# ------------------------------------------------------------------------------------------
+# full-width pins (SURVEY.md 8c protocol): weights reconstructed from seed by the consumer
+# ------------------------------------------------------------------------------------------
+FULL = {  # name: (res, alpha, batch)
+    "C1": (16, 1.0, 16), "C2": (64, 0.5, 64), "C3": (256, 1.0, 32), "C4": (512, 1.0, 16),
+}
+SURVEY_PINS = {  # (D_loss, score_real, score_fake, GP, G_loss) recorded in SURVEY.md 8(c)
+    "C1": (9.621342659, -0.006367247, -0.002287695, 9.617262840, 0.009899071),
+    "C2": (9.631142616, -0.018096786, -0.012321905, 9.625367165, 0.011696977),
+    "C3": (9.966442108, -0.023956211, -0.021933945, 9.964419365, 0.028972290),
+    "C4": (9.984798431, -0.018186904, -0.019845556, 9.986456871, 0.028318128),
+}
+
+
+def checksums(net):
+    return {k: np.array([float(v.double().sum()), float(v.double().abs().sum())]) for k, v in net.state_dict().items()
+            if v.numel() > 1}
+
+
+def full_fixture(models, config, name):
+    res, alpha, batch = FULL[name]
+    torch.manual_seed(1)
+    G = models.Generator_PG(config.N_gen_features, image_size_init=16)  # train.py:172
+    D = models.Discriminator_PG(config.N_dis_features, image_size_init=16)  # train.py:184
+    G.to(torch.device("cpu"), torch.float32)
+    D.to(torch.device("cpu"), torch.float32)
+    if res != 16:
+        G.set_resolution(res, alpha)
+        D.set_resolution(res, alpha)
+    oD = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    oG = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    out = {}
+    for k, v in checksums(G).items():
+        out["Ginit_cs/" + k] = v
+    for k, v in checksums(D).items():
+        out["Dinit_cs/" + k] = v
+    torch.manual_seed(123)
+    x = torch.rand(batch, 1, res, res) * 2 - 1
+    # RNG order of one iteration: z_d, z_gp, eps, z_g
+    z_d = latent(batch, 512)
+    z_gp = latent(batch, 512)
+    eps = torch.rand(batch, 1, 1, 1)
+    z_g = latent(batch, 512)
+    with torch.no_grad():
+        img = G(z_d)
+        out["G_of_z_d_slice"] = img[:2, 0, :8, :8].numpy()
+        out["G_of_z_d_stats"] = np.array([float(img.double().mean()), float(img.double().std())])
+        out["D_of_real"] = D(x).numpy()
+    cap = {}
+    scal, L = ref_step(G, D, oG, oD, x, z_d, z_gp, eps, z_g, capture=cap)
+    out["D_of_fake"] = L["fake_score"].detach().numpy()
+    out["grad_norms"] = L["norms"].detach().numpy()
+    for k, v in cap.items():
+        if k.startswith(("Dgrad/", "Ggrad/")):
+            out["cs/" + k] = np.array([float(v.astype(np.float64).sum()), float(np.abs(v.astype(np.float64)).sum())])
+    out["scalars"] = np.array([scal[k] for k in ("D_loss", "score_real", "score_fake", "GP", "G_loss")], dtype=np.float64)
+    for k, v in checksums(G).items():
+        out["Gafter_cs/" + k] = v
+    for k, v in checksums(D).items():
+        out["Dafter_cs/" + k] = v
+    out.update(z_d=z_d.numpy(), z_gp=z_gp.numpy(), z_g=z_g.numpy(), eps=eps.numpy())
+    out["real_cs"] = np.array([float(x.double().sum()), float(x.double().abs().sum())])
+    out["meta"] = np.array([res, alpha, 16, 512, batch, 1e-4], dtype=np.float64)
+    pins = np.array(SURVEY_PINS[name])
+    rel = np.abs(out["scalars"] - pins) / np.abs(pins)
+    print(f"full_{name}: scalars={out['scalars']}  max rel diff vs SURVEY pins = {rel.max():.2e}")
+    assert rel.max() < 5e-6, "harness replay disagrees with the reference's own loss modules (SURVEY pins)"
+    np.savez_compressed(os.path.join(OUT, f"full_{name}.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also regenerate the full-width C3/C4 pins (about a minute of CPU)")
+    ap.add_argument("--only", default="", help="comma list of fixture names")
+    args = ap.parse_args()
+    models, config = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    small = [("fresh4", 4, 1.0, 0), ("res8_init", 8, 1.0, 0), ("res8_warm", 8, 1.0, 40),
+             ("res16_fade_init", 16, 0.5, 0), ("res16_fade_warm", 16, 0.5, 40), ("res16_warm", 16, 1.0, 40)]
+    only = set(args.only.split(",")) - {""}
+    for name, res, alpha, warm in small:
+        if not only or name in only:
+            small_fixture(models, name, res, alpha, warm)
+    for name in (["C1", "C2"] + (["C3", "C4"] if args.full else [])):
+        if not only or name in only:
+            full_fixture(models, config, name)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""Pin the CPU oracle (oracle/pggan_oracle.py) against golden vectors captured from the reference's own
+models.py (oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_state
+from oracle import pggan_oracle as O
+
+SMALL = ["small_fresh4", "small_res8_init", "small_res8_warm", "small_res16_fade_init", "small_res16_fade_warm",
+         "small_res16_warm"]
+
+
+def _specs(fix):
+    res, alpha, init, latent, batch, lr = fix["meta"]
+    spec = O.NetSpec(image_size_init=int(init), slope=0.2, alpha=float(alpha))
+    return spec, int(batch), float(lr)
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_forward_matches_reference(name):
+    fix = load_golden(name)
+    spec, _, _ = _specs(fix)
+    pg = O.as_leaf_params(split_state(fix, "G/"))
+    pd = O.as_leaf_params(split_state(fix, "D/"))
+    with torch.no_grad():
+        img = O.generator_forward(pg, torch.from_numpy(fix["z_d"]), spec)
+        score = O.discriminator_forward(pd, torch.from_numpy(fix["real"]), spec)
+    assert _rel(img.numpy(), fix["G_of_z_d"]) < 2e-6
+    assert _rel(score.numpy(), fix["D_of_real"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_train_step_matches_reference(name):
+    fix = load_golden(name)
+    spec, batch, lr = _specs(fix)
+    pg = O.as_leaf_params(split_state(fix, "G/"))
+    pd = O.as_leaf_params(split_state(fix, "D/"))
+    t = lambda k: torch.from_numpy(fix[k])
+    # gradient penalty internals (loss_functions.py:175-176)
+    gp, norms = O.grad_penalty(pg, spec, pd, spec, t("real"), t("z_gp"), t("eps"), 10.0, return_norms=True)
+    assert _rel(norms.detach().numpy(), fix["grad_norms"]) < 5e-6
+    assert abs(float(gp.detach()) - fix["scalars"][3]) / abs(fix["scalars"][3]) < 5e-6
+    # one full iteration with per-parameter gradient capture
+    opt_g, opt_d = O.make_adam(pg, lr), O.make_adam(pd, lr)
+    O.zero_grads(pd)
+    d_loss, s_real, s_fake = O.d_w_loss(pg, spec, pd, spec, t("real"), t("z_d"), 0.001)
+    gp = O.grad_penalty(pg, spec, pd, spec, t("real"), t("z_gp"), t("eps"), 10.0)
+    (d_loss + gp).backward()
+    for k, v in split_state(fix, "Dgrad/").items():
+        assert _rel(pd[k].grad.numpy(), v) < 2e-5, k
+    opt_d.step()
+    O.zero_grads(pg)
+    O.zero_grads(pd)
+    g_loss = O.g_w_loss(pg, spec, pd, spec, t("z_g"))
+    g_loss.backward()
+    for k, v in split_state(fix, "Ggrad/").items():
+        assert _rel(pg[k].grad.numpy(), v) < 2e-5, k
+    opt_g.step()
+    got = np.array([float((d_loss + gp).detach()), float(s_real.detach()), float(s_fake.detach()), float(gp.detach()), float(g_loss.detach())])
+    assert np.allclose(got, fix["scalars"], rtol=5e-6, atol=1e-8)
+    # Adam moves every weight by ~lr; an update is g/(|g|+eps)-like, so compare the step itself loosely
+    for k, v in split_state(fix, "G_after/").items():
+        assert np.abs(pg[k].detach().numpy() - v).max() < 0.05 * lr, k
+    for k, v in split_state(fix, "D_after/").items():
+        if k != "alpha":
+            assert np.abs(pd[k].detach().numpy() - v).max() < 0.05 * lr, k
+
+
+def test_pixelnorm_second_order_fp64():
+    """gradcheck / gradgradcheck of the oracle PixelNorm∘LReLU (the only op with a non-zero Hessian)."""
+    torch.manual_seed(0)
+    x = torch.randn(2, 6, 3, 3, dtype=torch.float64, requires_grad=True)
+    f = lambda v: O.pixel_norm(O.lrelu(v, 0.2))
+    assert torch.autograd.gradcheck(f, (x,), atol=1e-6)
+    assert torch.autograd.gradgradcheck(f, (x,), atol=1e-6)
+
+
+def test_flop_model_matches_survey():
+    """F_G / F_D at the four stages (GFLOP per image per forward)."""
+    g = [128, 64, 32, 32, 16, 16]
+    d = [16, 16, 32, 32, 64, 128]
+    want = {(16, 1.0): (0.1091, 0.0756), (64, 0.5): (0.5624, 0.3024), (256, 1.0): (2.0741, 0.9081), (512, 1.0): (4.4963, 1.5184)}
+    for (res, alpha), (fg, fd) in want.items():
+        got = O.forward_flops(g, d, 16, res, 512, alpha)
+        assert abs(got[0] / 1e9 - fg) < 2e-4 and abs(got[1] / 1e9 - fd) < 2e-4, (res, got)
+
+
+def test_latent_sampler_pin():
+    """seed 7 -> z[0,:3]."""
+    torch.manual_seed(7)
+    z = O.sample_latent_vec((4, 512))
+    assert np.allclose(z[0, :3].numpy(), [-0.03830601, 0.01847874, 0.04198530], atol=1e-7)
+    assert np.allclose(z.norm(dim=1).numpy(), 1.0, atol=1e-6)
