@@ -1,0 +1,154 @@
+/*
+ * ngan.h -- C ABI of libngan_hip.so: hand-written gfx950 (MI355X) kernels for the PGGAN / WGAN-GP
+ * training step of oliviertrottier/neuron-gan.
+ *
+ * The reference has no FFI of its own: its hot path dispatches torch ATen operators from Python
+ * (SURVEY.md 2.1).  Each entry point below replaces one of those dispatch sites; the reference
+ * call site it stands in for is cited as file:line into /root/reference.  The reference-side
+ * binding a maintainer would add is a ctypes stub, shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every tensor is fp32, device memory, pixel-major / channels-last: (B, H, W, C) contiguous.
+ *     Images with C == 1 have the same bytes as the reference's NCHW tensors.
+ *   - weights keep the reference's parameter layouts (OIHW for convs, (out, in) for Linear), so
+ *     state_dict tensors are passed as they are.
+ *   - the caller allocates every output and workspace; the library never allocates, frees or
+ *     synchronises.  `stream` is a hipStream_t (PyTorch's current stream), passed as void*.
+ *   - return value: 0 ok; < 0 invalid argument / unsupported shape (see ngan_last_error());
+ *     > 0 a hipError_t from the launch.
+ *   - resample codes:  0 none, 1 avg-pool 2x2 on load, 2 bilinear x2 (align_corners=False) on load.
+ */
+#ifndef NGAN_H
+#define NGAN_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGAN_OK 0
+#define NGAN_ERR_ARG (-1)
+#define NGAN_ERR_SHAPE (-2)
+
+#define NGAN_RESAMPLE_NONE 0
+#define NGAN_RESAMPLE_POOL2 1
+#define NGAN_RESAMPLE_UP2 2
+
+const char* ngan_version(void);
+const char* ngan_last_error(void);
+
+/* ---- 3x3 convolution, pad 1, stride 1: Conv2d_normalized.forward, models.py:203-204 (ATen conv2d) ---------
+ * The kernels are an implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).  Weights are first re-ordered
+ * into MFMA fragment order and pre-multiplied by the equalised-LR constant `scale` (models.py:201).
+ *   mode 0 (forward):  k = Cin, n = Cout.
+ *   mode 1 (dgrad):    k = Cout, n = Cin, taps flipped: the same kernel then computes the input gradient.
+ * `packed` holds 9*Cin*Cout floats.  Cin and Cout must be multiples of 16. */
+int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int Cin, int mode, float scale, void* stream);
+
+/* y = epilogue(conv3x3(resample(x), packed) + bias)      (models.py:252-268 fused: resample, conv, LReLU, PixelNorm)
+ *   x        resample 0: (B,H,W,K)   1: (B,2H,2W,K)   2: (B,H/2,W/2,K)       (H, W: conv/output resolution)
+ *   bias     N floats or NULL
+ *   epilogue 0: y = conv (+bias)            1: y = PixelNorm(LeakyReLU(conv + bias)), rnorm (B,H,W) = sqrt(mean_c a^2 + eps)
+ *   out_mode 0: y is (B,H,W,N)              1: avg-pool adjoint store: y is (B,2H,2W,N), each value * 0.25 to its 2x2 block
+ * K = contraction channels, N = output channels (N <= 128 per call). */
+int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
+                     int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                     float slope, float eps, void* stream);
+
+/* weight gradient (ATen convolution_backward, weight part):
+ *   gw[co][ci][ky][kx] = scale * sum_{b,y,x} g[b,y,x,co] * resample(x)[b,y+ky-1,x+kx-1,ci]      gw is OIHW
+ * workspace: ngan_conv3x3_wgrad_workspace_bytes(...) bytes. */
+size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
+                       int B, int H, int W, int Cin, int Cout, int resample, float scale, void* stream);
+
+/* ---- LeakyReLU -> PixelNorm: models.py:263-264, 118-126 (ATen leaky_relu, pow, mean, sqrt, div) ---------------
+ * fwd:    a = lrelu(c + bias); r = sqrt(mean_c(a^2) + eps); y = a / r
+ * bwd:    gc = m * ((gy - y*mean_c(gy*y)) / r + gr*y/C),  m = (y > 0 ? 1 : slope); gr (npix) may be NULL
+ * bwdbwd: given h = dL/d(gc) of a bwd call made with gr == NULL:
+ *           ggy = (h' - y*t)/r,  gy_out = -(s*h' + t*gy)/r,  gr_out = -C*(u - s*t)/r^2
+ *           with h' = m*h, s = mean_c(gy*y), t = mean_c(h'*y), u = mean_c(h'*gy)
+ * C must be a multiple of 4 with C/4 a power of two <= 64. */
+int ngan_lrelu_pixelnorm_fwd(const float* c, const float* bias, float* y, float* rnorm, long npix, int C,
+                             float slope, float eps, void* stream);
+int ngan_lrelu_pixelnorm_bwd(const float* gy, const float* gr, const float* y, const float* rnorm, float* gc,
+                             long npix, int C, float slope, void* stream);
+int ngan_lrelu_pixelnorm_bwdbwd(const float* h, const float* gy, const float* y, const float* rnorm,
+                                float* ggy, float* gy_out, float* gr_out, long npix, int C, float slope, void* stream);
+
+/* column sums over pixels: out[c] = scale * sum_p g[p][c]   (bias gradient of conv2d).  workspace: 1024*C floats */
+int ngan_channel_sum(const float* g, float* out, float* workspace, long npix, int C, float scale, void* stream);
+
+/* ---- FromImage 1x1 conv + bias: models.py:161-165 ---------------------------------------------------------------
+ * fwd: y[p][c] = sum_k w[c][k]*x[p][k] + b[c];  pool=1: x is (B,2H,2W,Ncol) and is 2x2-averaged on load (models.py:519)
+ * dx:  gx[p][k] = sum_c w[c][k]*g[p][c];        pool=1: gx is (B,2H,2W,Ncol), avg-pool adjoint store
+ * dw:  gw[c][k] = sum_p g[p][c]*x[p][k], gb[c] = sum_p g[p][c] (gb may be NULL).  workspace: 1024*C*(Ncol+1) floats */
+int ngan_from_image_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int Ncol, int C,
+                        int pool, void* stream);
+int ngan_from_image_dx(const float* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool, void* stream);
+int ngan_from_image_dw(const float* x, const float* g, float* gw, float* gb, float* workspace,
+                       int B, int H, int W, int Ncol, int C, int pool, void* stream);
+
+/* ---- ToImage 1x1 conv + tanh: models.py:141-149 ------------------------------------------------------------------
+ * fwd: t[p][k] = tanh(sum_c w[k][c]*x[p][c])
+ * bwd: q = g*(1-t^2); gx[p][c] = sum_k q[p][k]*w[k][c]; gw[k][c] = sum_p q[p][k]*x[p][c].  workspace: 1024*C*Ncol floats */
+int ngan_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, void* stream);
+int ngan_to_image_bwd(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
+                      float* workspace, long npix, int C, int Ncol, void* stream);
+
+/* ---- resampling: models.py:87-89 (F.interpolate bilinear, align_corners=None) and models.py:254 (AvgPool2d(2)) --
+ * (h, w) is always the LOW resolution; adjoint = transpose of the linear map. */
+int ngan_up2_fwd(const float* x, float* y, int B, int h, int w, int C, void* stream);
+int ngan_up2_adjoint(const float* gy, float* gx, int B, int h, int w, int C, void* stream);
+int ngan_pool2_fwd(const float* x, float* y, int B, int h, int w, int C, void* stream);
+int ngan_pool2_adjoint(const float* gy, float* gx, int B, int h, int w, int C, void* stream);
+
+/* ---- fade-in and interpolation arithmetic: models.py:350, 521; loss_functions.py:171 -----------------------------
+ * lerp:   out = a + alpha*(b - a), alpha read from device memory (so a captured graph follows the transition)
+ * axpby:  out = ca*a + cb*b with host scalars (b may be NULL -> out = ca*a)
+ * fade_bwd: ga = (1-alpha)*g, gb = alpha*g
+ * xhat:   out[b,:] = eps[b]*real[b,:] + (1-eps[b])*fake[b,:] */
+int ngan_lerp(const float* a, const float* b, const float* alpha, float* out, long n, void* stream);
+int ngan_axpby(const float* a, const float* b, float ca, float cb, float* out, long n, void* stream);
+int ngan_fade_bwd(const float* g, const float* alpha, float* ga, float* gb, long n, void* stream);
+int ngan_xhat(const float* real, const float* fake, const float* eps, float* out, int B, long n, void* stream);
+
+/* ---- gradient penalty pieces: loss_functions.py:176 (ATen linalg_vector_norm) ----------------------------------
+ * norms[b] = ||g[b,:]||_2 ;   scale_rows: out[b,:] = coef[b] * g[b,:] */
+int ngan_sample_l2norm(const float* g, float* norms, int B, long n, void* stream);
+int ngan_scale_rows(const float* g, const float* coef, float* out, int B, long n, void* stream);
+
+/* ---- generator stem: Linear_normalized -> Unflatten -> LeakyReLU -> PixelNorm, models.py:299-311 (ATen mm) --------
+ * fwd:   y[b][p][c] = PN(LReLU(scale * sum_k z[b][k] * Wt[c*S + p][k])),  y (B,S,C), rnorm (B,S); W is (C*S, K)
+ * wgrad: gW[c*S+p][k] = scale * sum_b gc[b][p][c] * z[b][k]
+ * dgrad: gz[b][k] = scale * sum_{p,c} gc[b][p][c] * W[c*S+p][k] */
+int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* y, float* rnorm, int B, int K, int S, int C,
+                             float scale, float slope, float eps, void* stream);
+int ngan_linear_wgrad(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale, void* stream);
+int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream);
+
+/* ---- critic head: Conv2d_normalized(C, 1, (S,S), padding 0) + Flatten, models.py:485-490 ------------------------
+ * fwd: out[b] = scale * sum_{p,c} y[b][p][c]*W[c*S2+p] + bias[0]
+ * dx:  gy[b][p][c] = scale * go[b] * W[c*S2+p]
+ * dw:  gW[c*S2+p] = scale * sum_b go[b]*y[b][p][c];  gb[0] = sum_b go[b] */
+int ngan_final_dot_fwd(const float* y, const float* W, const float* bias, float* out, int B, int S2, int C, float scale, void* stream);
+int ngan_final_dot_dx(const float* go, const float* W, float* gy, int B, int S2, int C, float scale, void* stream);
+int ngan_final_dot_dw(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, void* stream);
+
+/* ---- Adam: optim.Adam.step, train.py:224-225, 366, 385 (betas (beta1, 0.999), eps 1e-8, no weight decay) ---------
+ * One launch updates every active segment of a flat parameter buffer.
+ *   seg_off[i], seg_len[i]  element offset / length of tensor i inside p, g, m, v   (device, int64)
+ *   seg_active[i]           1 if tensor i received a gradient this step (inactive tensors keep step and state)
+ *   seg_step[i]             per-tensor step count (device float, incremented here for active tensors)
+ *   hyper                   device floats {lr, beta1, beta2, eps, grad_scale}; the gradient is multiplied by grad_scale
+ *                           (1/world_size after a SUM all-reduce across data-parallel ranks, otherwise 1)
+ * chunk_seg / chunk_off (device int32 / int64): work list, one entry per 4096-element chunk. */
+int ngan_adam_step(float* p, const float* g, float* m, float* v, const long* seg_off, const long* seg_len,
+                   const int* seg_active, float* seg_step, int n_seg, const int* chunk_seg, const long* chunk_off,
+                   int n_chunks, const float* hyper, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGAN_H */

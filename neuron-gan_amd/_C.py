@@ -1,0 +1,111 @@
+"""ctypes binding of libngan_hip.so (C ABI: include/ngan.h).
+
+There is no CPU fallback: if the shared library is missing, or a tensor is not a contiguous fp32 CUDA
+tensor, the call raises.  PyTorch is used only for device memory and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libngan_hip.so")
+
+_P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+
+# name -> argument types (the trailing void* stream included), mirroring include/ngan.h
+SIGNATURES = {
+    "ngan_conv3x3_pack_weights": [_P, _P, _I, _I, _I, _F, _P],
+    "ngan_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
+    "ngan_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "ngan_lrelu_pixelnorm_fwd": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
+    "ngan_lrelu_pixelnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "ngan_lrelu_pixelnorm_bwdbwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "ngan_channel_sum": [_P, _P, _P, _L, _I, _F, _P],
+    "ngan_from_image_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ngan_from_image_dx": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ngan_from_image_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ngan_to_image_fwd": [_P, _P, _P, _L, _I, _I, _P],
+    "ngan_to_image_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "ngan_up2_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "ngan_up2_adjoint": [_P, _P, _I, _I, _I, _I, _P],
+    "ngan_pool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "ngan_pool2_adjoint": [_P, _P, _I, _I, _I, _I, _P],
+    "ngan_lerp": [_P, _P, _P, _P, _L, _P],
+    "ngan_axpby": [_P, _P, _F, _F, _P, _L, _P],
+    "ngan_fade_bwd": [_P, _P, _P, _P, _L, _P],
+    "ngan_xhat": [_P, _P, _P, _P, _I, _L, _P],
+    "ngan_sample_l2norm": [_P, _P, _I, _L, _P],
+    "ngan_scale_rows": [_P, _P, _P, _I, _L, _P],
+    "ngan_linear_lrelu_pn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P],
+    "ngan_linear_wgrad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "ngan_linear_dgrad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "ngan_final_dot_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "ngan_final_dot_dx": [_P, _P, _P, _I, _I, _I, _F, _P],
+    "ngan_final_dot_dw": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "ngan_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
+}
+NON_STATUS = {
+    "ngan_version": ([], ctypes.c_char_p),
+    "ngan_last_error": ([], ctypes.c_char_p),
+    "ngan_conv3x3_wgrad_workspace_bytes": ([_I, _I, _I, _I, _I], _Z),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libngan_hip.so once.  Raises RuntimeError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               f"or `make -C neuron-gan_amd/csrc`; there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        for name, (argtypes, restype) in NON_STATUS.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(SIGNATURES) + list(NON_STATUS)
+
+
+def version() -> str:
+    return lib().ngan_version().decode()
+
+
+def _ptr(t, name):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor or None, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the HIP path needs CUDA/HIP device memory (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous, got strides {t.stride()} for shape {tuple(t.shape)}")
+    return t.data_ptr()
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point on PyTorch's current stream; tensors are passed by data pointer."""
+    fn = getattr(lib(), name)
+    conv = []
+    for i, a in enumerate(args):
+        conv.append(_ptr(a, f"{name} arg {i}") if (a is None or isinstance(a, torch.Tensor)) else a)
+    stream = torch.cuda.current_stream().cuda_stream
+    status = fn(*conv, stream)
+    if status != 0:
+        msg = lib().ngan_last_error().decode()
+        raise RuntimeError(f"{name} failed with status {status}: {msg}")
+
+
+def wgrad_workspace_bytes(B, H, W, Cin, Cout) -> int:
+    return int(lib().ngan_conv3x3_wgrad_workspace_bytes(B, H, W, Cin, Cout))

@@ -1,0 +1,430 @@
+// 3x3 convolution (pad 1, stride 1) on channels-last fp32 tensors as an implicit GEMM on
+// v_mfma_f32_16x16x4_f32 (exact fp32 MFMA, gfx950).  Replaces ATen conv2d / convolution_backward at
+// /root/reference/models.py:203-204 and its autograd.
+//
+// Forward / input-gradient kernel ("D^T" formulation): one MFMA computes a 16(cout) x 16(pixel) tile, the
+// contraction runs over (tap, cin).  A = weights (pre-packed in fragment order, pre-scaled), B = pixels read
+// from an LDS-staged halo tile with one ds_read_b128 per 4 MFMAs (the k-order inside a 16-channel group is
+// permuted identically on both operands, which an MFMA does not care about).  The accumulator then holds, per
+// lane, 4 consecutive output channels of one pixel, so the epilogue (bias, LeakyReLU, PixelNorm) reduces over
+// channels with two shuffles and stores 16 B per lane, fully coalesced.
+// The avg-pool / bilinear-x2 resampling in front of a block's first conv (models.py:254, 257) is applied
+// while the halo tile is staged, so the resampled tensor never exists in HBM.
+#include "ngan_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, HALO_H = TH + 2, HALO_W = TW + 2;
+
+struct ConvArgs {
+    const float* x; const float* wp; const float* bias; float* y; float* rn;
+    int B, H, W, K, N, tiles_x, tiles_y;
+    float slope, eps;
+};
+
+// 4 consecutive channels (starting at ch) of conv-input pixel (gy, gx) of image b, after resampling.
+// C = channel count of x.  Out-of-image pixels are the conv's zero padding.
+template <int RES>
+__device__ __forceinline__ float4 load_resampled(const float* __restrict__ x, int b, int gy, int gx, int ch,
+                                                 int H, int W, int C) {
+    if (gy < 0 || gy >= H || gx < 0 || gx >= W) return f4zero();
+    if (RES == NGAN_RESAMPLE_NONE) {
+        return ld4(x + (((long)b * H + gy) * W + gx) * C + ch);
+    } else if (RES == NGAN_RESAMPLE_POOL2) {
+        const long W2 = 2L * W;
+        const float* p = x + (((long)b * 2 * H + 2 * gy) * W2 + 2 * gx) * C + ch;
+        float4 v = f4add(f4add(ld4(p), ld4(p + C)), f4add(ld4(p + W2 * C), ld4(p + W2 * C + C)));
+        return f4scale(v, 0.25f);
+    } else {
+        const int h = H >> 1, w = W >> 1;
+        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+        up2_taps(gy, h, y0, y1, wy0, wy1);
+        up2_taps(gx, w, x0, x1, wx0, wx1);
+        const float* r0 = x + ((long)b * h + y0) * w * C + ch;
+        const float* r1 = x + ((long)b * h + y1) * w * C + ch;
+        float4 top = f4fma(ld4(r0 + (long)x1 * C), wx1, f4scale(ld4(r0 + (long)x0 * C), wx0));
+        float4 bot = f4fma(ld4(r1 + (long)x1 * C), wx1, f4scale(ld4(r1 + (long)x0 * C), wx0));
+        return f4fma(bot, wy1, f4scale(top, wy0));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing: OIHW -> [tap][k-group g][n-tile mt][lane][4], value * scale.
+// lane l of (tap, g, mt) holds n = 16*mt + (l & 15) and k = 16*g + 4*(l >> 4) + i, i = 0..3.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin,
+                                    int mode, float scale) {
+    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    const int G = K / 16, MT = N / 16;
+    const long total = 9L * K * N;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = idx & 3, lane = (idx >> 2) & 63;
+    long r = idx >> 8;
+    const int mt = r % MT; r /= MT;
+    const int g = r % G;
+    const int tap = r / G;
+    const int n = mt * 16 + (lane & 15), k = g * 16 + 4 * (lane >> 4) + i;
+    float v;
+    if (mode == 0) v = w[((long)n * Cin + k) * 9 + tap];          // co = n, ci = k
+    else           v = w[((long)k * Cin + n) * 9 + (8 - tap)];    // co = k, ci = n, taps flipped
+    packed[idx] = v * scale;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward / dgrad kernel.  256 threads = 4 waves; tile = 8 x 32 output pixels x all N = 16*MT channels.
+// wave w owns tile rows 2w, 2w+1 -> 4 pixel groups of 16 consecutive pixels.
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, int RES, int EPI, int OUTMODE>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[HALO_H * HALO_W * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    int t = blockIdx.x;
+    const int txi = t % a.tiles_x; t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    const int G = a.K >> 4;
+
+    f32x4 acc[4][MT];
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int g = 0; g < G; ++g) {
+        __syncthreads();
+        for (int e = tid; e < HALO_H * HALO_W * 4; e += 256) {
+            const int pix = e >> 2, c4 = e & 3;
+            const int ty = pix / HALO_W, tx = pix - ty * HALO_W;
+            float4 v = load_resampled<RES>(a.x, b, y0 + ty - 1, x0 + tx - 1, g * 16 + c4 * 4, a.H, a.W, a.K);
+            st4(&tile[pix * 16 + c4 * 4], v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            float xv[4][4];
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) {
+                const int row = wave * 2 + (pg >> 1), col = (pg & 1) * 16 + p;
+                float4 v = ld4(&tile[((row + dy) * HALO_W + col + dx) * 16 + q * 4]);
+                xv[pg][0] = v.x; xv[pg][1] = v.y; xv[pg][2] = v.z; xv[pg][3] = v.w;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float4 wv4 = ld4(a.wp + ((((long)tap * G + g) * MT + mt) * 64 + lane) * 4);
+                const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pg = 0; pg < 4; ++pg)
+                        acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i], xv[pg][i], acc[pg][mt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds channels mt*16 + 4q + {0..3} of pixel (row, col) ----
+    float4 bv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bv[mt] = a.bias ? ld4(a.bias + mt * 16 + q * 4) : f4zero();
+    const float inv_n = 1.0f / (float)a.N;
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) {
+        const int row = wave * 2 + (pg >> 1), col = (pg & 1) * 16 + p;
+        const int gy = y0 + row, gx = x0 + col;
+        const bool valid = gy < a.H && gx < a.W;
+        float4 v[MT];
+        float ss = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float4 c = make_float4(acc[pg][mt][0] + bv[mt].x, acc[pg][mt][1] + bv[mt].y,
+                                   acc[pg][mt][2] + bv[mt].z, acc[pg][mt][3] + bv[mt].w);
+            if (EPI == 1) {
+                c.x = c.x > 0.f ? c.x : a.slope * c.x; c.y = c.y > 0.f ? c.y : a.slope * c.y;
+                c.z = c.z > 0.f ? c.z : a.slope * c.z; c.w = c.w > 0.f ? c.w : a.slope * c.w;
+                ss += f4dot(c, c);
+            }
+            v[mt] = c;
+        }
+        if (EPI == 1) {
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float r = sqrtf(ss * inv_n + a.eps);
+            const float inv = 1.0f / r;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) v[mt] = f4scale(v[mt], inv);
+            if (valid && q == 0) a.rn[((long)b * a.H + gy) * a.W + gx] = r;
+        }
+        if (valid) {
+            if (OUTMODE == 0) {
+                float* o = a.y + (((long)b * a.H + gy) * a.W + gx) * a.N + q * 4;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) st4(o + mt * 16, v[mt]);
+            } else {
+                const long W2 = 2L * a.W;
+                float* o = a.y + (((long)b * 2 * a.H + 2 * gy) * W2 + 2 * gx) * a.N + q * 4;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float4 s = f4scale(v[mt], 0.25f);
+                    st4(o + mt * 16, s); st4(o + a.N + mt * 16, s);
+                    st4(o + W2 * a.N + mt * 16, s); st4(o + W2 * a.N + a.N + mt * 16, s);
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int RES, int EPI, int OUTMODE>
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    const int grid = a.B * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL((conv3x3_kernel<MT, RES, EPI, OUTMODE>), dim3(grid), dim3(256), 0, s, a);
+    return ngan::launch_status("ngan_conv3x3_fwd");
+}
+
+template <int MT>
+int dispatch_conv(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
+    if (outmode == 1) return launch_conv<MT, 0, 0, 1>(a, s);
+    switch (res * 2 + epi) {
+        case 0: return launch_conv<MT, 0, 0, 0>(a, s);
+        case 1: return launch_conv<MT, 0, 1, 0>(a, s);
+        case 2: return launch_conv<MT, 1, 0, 0>(a, s);
+        case 3: return launch_conv<MT, 1, 1, 0>(a, s);
+        case 4: return launch_conv<MT, 2, 0, 0>(a, s);
+        default: return launch_conv<MT, 2, 1, 0>(a, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient.  D[co][ci] (per tap) += sum_pixels g[pix][co] * xin[pix + tap][ci]: the MFMA contraction
+// runs over pixels (4 per instruction).  A block owns a (<=32 couts) x (<=32 cins) slice of the output and
+// walks pixel tiles grid-stride; the 4 waves split the tile rows, are summed through LDS at the end, and
+// each block writes one partial slab; wgrad_reduce_kernel sums the slabs in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x; const float* g; float* partial;
+    int B, H, W, K, N, tiles_x, tiles_y, n_tiles, n_ci_slices;
+};
+
+template <int CS>
+__device__ __forceinline__ int swz(int pix, int c) { return CS == 32 ? (c ^ ((pix & 1) << 4)) : c; }
+
+template <int COT, int CIT, int RES>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int CO_S = COT * 16, CI_S = CIT * 16;
+    constexpr int G_ELEMS = TH * TW * CO_S, X_ELEMS = HALO_H * HALO_W * CI_S;
+    constexpr int NACC = 9 * COT * CIT;
+    constexpr int RED_ELEMS = NACC * 64 * 4;
+    constexpr int SMEM = (G_ELEMS + X_ELEMS) > RED_ELEMS ? (G_ELEMS + X_ELEMS) : RED_ELEMS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* g_lds = smem;
+    float* x_lds = smem + G_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int slice = blockIdx.y;
+    const int co0 = (slice / a.n_ci_slices) * CO_S, ci0 = (slice % a.n_ci_slices) * CI_S;
+
+    f32x4 acc[9][COT][CIT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+#pragma unroll
+            for (int j = 0; j < CIT; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        int t = tile;
+        const int txi = t % a.tiles_x; t /= a.tiles_x;
+        const int tyi = t % a.tiles_y;
+        const int b = t / a.tiles_y;
+        const int y0 = tyi * TH, x0 = txi * TW;
+        __syncthreads();
+        for (int e = tid; e < TH * TW * (CO_S / 4); e += 256) {
+            const int pix = e / (CO_S / 4), c4 = e % (CO_S / 4);
+            const int r = pix / TW, c = pix % TW;
+            const int gy = y0 + r, gx = x0 + c;
+            float4 v = (gy < a.H && gx < a.W) ? ld4(a.g + (((long)b * a.H + gy) * a.W + gx) * a.N + co0 + c4 * 4) : f4zero();
+            st4(&g_lds[pix * CO_S + swz<CO_S>(pix, c4 * 4)], v);
+        }
+        for (int e = tid; e < HALO_H * HALO_W * (CI_S / 4); e += 256) {
+            const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
+            const int ty = pix / HALO_W, tx = pix - ty * HALO_W;
+            float4 v = load_resampled<RES>(a.x, b, y0 + ty - 1, x0 + tx - 1, ci0 + c4 * 4, a.H, a.W, a.K);
+            st4(&x_lds[pix * CI_S + swz<CI_S>(pix, c4 * 4)], v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wave * 2 + rr;
+            for (int s = 0; s < TW / 4; ++s) {
+                float av[COT];
+                const int gp = r * TW + 4 * s + q;
+#pragma unroll
+                for (int i = 0; i < COT; ++i) av[i] = g_lds[gp * CO_S + swz<CO_S>(gp, i * 16 + p)];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3, dx = tap % 3;
+                    const int xp = (r + dy) * HALO_W + 4 * s + q + dx;
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j) {
+                        const float bvv = x_lds[xp * CI_S + swz<CI_S>(xp, j * 16 + p)];
+#pragma unroll
+                        for (int i = 0; i < COT; ++i)
+                            acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bvv, acc[tap][i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- sum the 4 waves through LDS (fixed order), then write this block's slab ----
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < COT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j) {
+                        const int idx = (t * COT + i) * CIT + j;
+                        float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
+                        if (w > 0) v = f4add(v, red[idx * 64 + lane]);
+                        red[idx * 64 + lane] = v;
+                    }
+        }
+        __syncthreads();
+    }
+    float* slab = a.partial + ((long)blockIdx.x * gridDim.y + slice) * (9 * CO_S * CI_S);
+    for (int e = tid; e < NACC * 64; e += 256) {
+        const int idx = e >> 6, l = e & 63;
+        const float4 v = red[e];
+        const int tap = idx / (COT * CIT), i = (idx / CIT) % COT, j = idx % CIT;
+        const int ci_l = j * 16 + (l & 15), co_l = i * 16 + 4 * (l >> 4);
+        float* o = slab + ((long)tap * CO_S + co_l) * CI_S + ci_l;
+        o[0] = v.x; o[CI_S] = v.y; o[2 * CI_S] = v.z; o[3 * CI_S] = v.w;
+    }
+}
+
+// out[(co*K + ci)*9 + tap] = scale * sum_parts slab[part][slice][tap][co_l][ci_l]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
+                                                           int nparts, int nslices, int n_ci_slices, int CO_S, int CI_S,
+                                                           int K, float scale) {
+    __shared__ float red[256];
+    const int slab = 9 * CO_S * CI_S;
+    const long M = (long)nslices * slab;
+    const int tid = threadIdx.x;
+    const long i = (long)blockIdx.x * 64 + (tid & 63);
+    float s = 0.f;
+    if (i < M)
+        for (int j = tid >> 6; j < nparts; j += 4) s += partial[(long)j * M + i];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 64 && i < M) {
+        s = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+        int r = (int)(i % slab);
+        const int slice = (int)(i / slab);
+        const int ci_l = r % CI_S; r /= CI_S;
+        const int co_l = r % CO_S;
+        const int tap = r / CO_S;
+        const int co = (slice / n_ci_slices) * CO_S + co_l, ci = (slice % n_ci_slices) * CI_S + ci_l;
+        gw[((long)co * K + ci) * 9 + tap] = s * scale;
+    }
+}
+
+struct WgradPlan { int co_s, ci_s, nslices, n_ci_slices, tiles_x, tiles_y, n_tiles, nwx; };
+
+WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
+    WgradPlan p;
+    p.co_s = (Cout % 32 == 0) ? 32 : 16;
+    p.ci_s = (Cin % 32 == 0) ? 32 : 16;
+    p.n_ci_slices = Cin / p.ci_s;
+    p.nslices = (Cout / p.co_s) * p.n_ci_slices;
+    p.tiles_x = ngan::ceil_div(W, TW);
+    p.tiles_y = ngan::ceil_div(H, TH);
+    p.n_tiles = B * p.tiles_x * p.tiles_y;
+    int cap = 1024 / p.nslices;
+    if (cap < 1) cap = 1;
+    p.nwx = p.n_tiles < cap ? p.n_tiles : cap;
+    return p;
+}
+
+template <int COT, int CIT>
+int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, hipStream_t s) {
+    dim3 grid(p.nwx, p.nslices);
+    if (res == 0) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 0>), grid, dim3(256), 0, s, a);
+    else if (res == 1) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 2>), grid, dim3(256), 0, s, a);
+    return ngan::launch_status("ngan_conv3x3_wgrad");
+}
+
+}  // namespace
+
+extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int Cin, int mode, float scale,
+                                         void* stream) {
+    NGAN_REQUIRE(w_oihw && packed, NGAN_ERR_ARG, "conv3x3_pack_weights: null pointer");
+    NGAN_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0, NGAN_ERR_SHAPE,
+                 "conv3x3_pack_weights: Cin=%d, Cout=%d must be positive multiples of 16", Cin, Cout);
+    NGAN_REQUIRE(mode == 0 || mode == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: mode %d", mode);
+    const long total = 9L * Cin * Cout;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ngan::ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, packed, Cout, Cin, mode, scale);
+    return ngan::launch_status("ngan_conv3x3_pack_weights");
+}
+
+extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
+                                int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                                float slope, float eps, void* stream) {
+    NGAN_REQUIRE(x && packed && y, NGAN_ERR_ARG, "conv3x3_fwd: null pointer");
+    NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_fwd: bad dims B=%d H=%d W=%d", B, H, W);
+    NGAN_REQUIRE(K > 0 && K % 16 == 0, NGAN_ERR_SHAPE, "conv3x3_fwd: K=%d must be a positive multiple of 16", K);
+    NGAN_REQUIRE(N == 16 || N == 32 || N == 64 || N == 128, NGAN_ERR_SHAPE, "conv3x3_fwd: N=%d must be 16/32/64/128", N);
+    NGAN_REQUIRE(resample >= 0 && resample <= 2, NGAN_ERR_ARG, "conv3x3_fwd: resample %d", resample);
+    NGAN_REQUIRE(epilogue == 0 || epilogue == 1, NGAN_ERR_ARG, "conv3x3_fwd: epilogue %d", epilogue);
+    NGAN_REQUIRE(out_mode == 0 || (out_mode == 1 && epilogue == 0 && resample == 0), NGAN_ERR_ARG,
+                 "conv3x3_fwd: out_mode %d needs epilogue 0 and resample 0", out_mode);
+    NGAN_REQUIRE(epilogue == 0 || rnorm, NGAN_ERR_ARG, "conv3x3_fwd: epilogue 1 needs rnorm");
+    NGAN_REQUIRE(resample != NGAN_RESAMPLE_UP2 || (H % 2 == 0 && W % 2 == 0), NGAN_ERR_SHAPE,
+                 "conv3x3_fwd: bilinear x2 needs even H, W");
+    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, ngan::ceil_div(W, TW), ngan::ceil_div(H, TH), slope, eps};
+    hipStream_t s = (hipStream_t)stream;
+    switch (N / 16) {
+        case 1: return dispatch_conv<1>(a, resample, epilogue, out_mode, s);
+        case 2: return dispatch_conv<2>(a, resample, epilogue, out_mode, s);
+        case 4: return dispatch_conv<4>(a, resample, epilogue, out_mode, s);
+        default: return dispatch_conv<8>(a, resample, epilogue, out_mode, s);
+    }
+}
+
+extern "C" size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % 16) return 0;
+    WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
+    return (size_t)p.nwx * p.nslices * 9 * p.co_s * p.ci_s * sizeof(float);
+}
+
+extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
+                                  int B, int H, int W, int Cin, int Cout, int resample, float scale, void* stream) {
+    NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "conv3x3_wgrad: null pointer");
+    NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_wgrad: bad dims B=%d H=%d W=%d", B, H, W);
+    NGAN_REQUIRE(Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
+                 "conv3x3_wgrad: Cin=%d, Cout=%d must be positive multiples of 16", Cin, Cout);
+    NGAN_REQUIRE(resample >= 0 && resample <= 2, NGAN_ERR_ARG, "conv3x3_wgrad: resample %d", resample);
+    NGAN_REQUIRE(resample != NGAN_RESAMPLE_UP2 || (H % 2 == 0 && W % 2 == 0), NGAN_ERR_SHAPE,
+                 "conv3x3_wgrad: bilinear x2 needs even H, W");
+    WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
+    WgradArgs a{x, g, workspace, B, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.n_tiles, p.n_ci_slices};
+    hipStream_t s = (hipStream_t)stream;
+    int st;
+    if (p.co_s == 32 && p.ci_s == 32) st = launch_wgrad<2, 2>(a, p, resample, s);
+    else if (p.co_s == 32) st = launch_wgrad<2, 1>(a, p, resample, s);
+    else if (p.ci_s == 32) st = launch_wgrad<1, 2>(a, p, resample, s);
+    else st = launch_wgrad<1, 1>(a, p, resample, s);
+    if (st) return st;
+    const long M = (long)p.nslices * 9 * p.co_s * p.ci_s;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ngan::ceil_div(M, 64)), dim3(256), 0, s, workspace, gw, p.nwx,
+                       p.nslices, p.n_ci_slices, p.co_s, p.ci_s, Cin, scale);
+    return ngan::launch_status("ngan_conv3x3_wgrad(reduce)");
+}

@@ -1,0 +1,64 @@
+// Shared helpers for the gfx950 kernels behind include/ngan.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include "../../include/ngan.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace ngan {
+
+void set_error(const char* fmt, ...);
+
+// status of the launch just issued on this thread: 0 or the hipError_t
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return NGAN_OK;
+}
+
+#define NGAN_REQUIRE(cond, code, ...)          \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::ngan::set_error(__VA_ARGS__);    \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// stage-2 of every two-stage reduction: out[i] = scale * sum_j partials[j*M + i]
+int reduce_partials(const float* partials, int nparts, int M, float* out, float scale, hipStream_t s);
+
+}  // namespace ngan
+
+// ---- device helpers ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 f4fma(float4 a, float s, float4 c) {
+    return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+__device__ __forceinline__ float f4dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// butterfly sum over groups of `width` consecutive lanes (width a power of two <= 64)
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Bilinear x2 (align_corners=False) source taps for output index d (0 <= d < 2n):
+// out[d] = w0*in[i0] + w1*in[i1]     (models.py:87-89 -> ATen upsample_bilinear2d)
+__device__ __forceinline__ void up2_taps(int d, int n, int& i0, int& i1, float& w0, float& w1) {
+    int i = d >> 1;
+    if (d & 1) { i0 = i; i1 = min(i + 1, n - 1); w0 = 0.75f; w1 = 0.25f; }
+    else       { i0 = max(i - 1, 0); i1 = i; w0 = 0.25f; w1 = 0.75f; }
+}

@@ -1,0 +1,524 @@
+// HBM-bound helpers around the conv stack: 1x1 colour projections (FromImage / ToImage), standalone
+// resampling and its adjoint, fade-in arithmetic, gradient-penalty norms, channel sums.
+// Reference call sites: /root/reference/models.py:141-149 (ToImage), 161-165 (FromImage), 87-89 (Interpolate),
+// 254 (AvgPool2d), 350 / 521 (fade-in); loss_functions.py:171, 176 (x_hat, per-sample gradient norm).
+#include "ngan_common.h"
+
+namespace ngan {
+
+// out[i] = scale * sum_j partials[j*stride + i], i < M.  Fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int M,
+                                                              long stride, float* __restrict__ out, float scale) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const long i = (long)blockIdx.x * 64 + (tid & 63);
+    float s = 0.f;
+    if (i < M)
+        for (int j = tid >> 6; j < nparts; j += 4) s += partials[(long)j * stride + i];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 64 && i < M) out[i] = ((red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192])) * scale;
+}
+
+int reduce_partials_strided(const float* partials, int nparts, int M, long stride, float* out, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(M, 64)), dim3(256), 0, s, partials, nparts, M, stride, out, scale);
+    return launch_status("reduce_partials");
+}
+
+int reduce_partials(const float* partials, int nparts, int M, float* out, float scale, hipStream_t s) {
+    return reduce_partials_strided(partials, nparts, M, M, out, scale, s);
+}
+
+}  // namespace ngan
+
+namespace {
+
+using ngan::ceil_div;
+constexpr int MAX_PARTS = 1024;
+
+bool pow2_quads(int C) {
+    if (C <= 0 || C % 4) return false;
+    const int q = C / 4;
+    return q <= 64 && (q & (q - 1)) == 0;
+}
+
+int stream_blocks(long npix, int Q) {
+    long need = (npix * Q + 255) / 256;
+    return (int)(need < MAX_PARTS ? need : MAX_PARTS);
+}
+
+// block-level column reduction: every thread holds a float4 for channel-quad (tid % Q); threads with the same
+// quad are summed; result for quad k is returned to thread k (k < Q).
+template <int Q>
+__device__ __forceinline__ float4 block_quad_sum(float4 v, float4* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    float4 s = f4zero();
+    if (tid < Q)
+        for (int j = tid; j < 256; j += Q) s = f4add(s, red[j]);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// channel sums (bias gradient)
+// ------------------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ partial,
+                                                          long npix, int C) {
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x, sub = tid % Q;
+    const long stride = (long)gridDim.x * (256 / Q);
+    float4 acc = f4zero();
+    for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) acc = f4add(acc, ld4(g + pix * C + sub * 4));
+    float4 s = block_quad_sum<Q>(acc, red);
+    if (tid < Q) st4(partial + (long)blockIdx.x * C + tid * 4, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// FromImage
+// ------------------------------------------------------------------------------------------------------------
+template <int POOL>
+__device__ __forceinline__ float load_img(const float* __restrict__ x, int b, int yy, int xx, int k, int H, int W, int Ncol) {
+    if (POOL == 0) return x[(((long)b * H + yy) * W + xx) * Ncol + k];
+    const long W2 = 2L * W;
+    const float* p = x + (((long)b * 2 * H + 2 * yy) * W2 + 2 * xx) * Ncol + k;
+    return 0.25f * ((p[0] + p[Ncol]) + (p[W2 * Ncol] + p[W2 * Ncol + Ncol]));
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void from_image_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int B, int H, int W, int Ncol, int C) {
+    const int Q = C / 4;
+    const long total = (long)B * H * W * Q;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const long pix = gid / Q;
+        const int c0 = (int)(gid % Q) * 4;
+        const int xx = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        const int b = (int)(pix / ((long)W * H));
+        float4 o = bias ? ld4(bias + c0) : f4zero();
+        for (int k = 0; k < Ncol; ++k) {
+            const float v = load_img<POOL>(x, b, yy, xx, k, H, W, Ncol);
+            o.x = fmaf(w[(c0 + 0) * Ncol + k], v, o.x); o.y = fmaf(w[(c0 + 1) * Ncol + k], v, o.y);
+            o.z = fmaf(w[(c0 + 2) * Ncol + k], v, o.z); o.w = fmaf(w[(c0 + 3) * Ncol + k], v, o.w);
+        }
+        st4(y + pix * C + c0, o);
+    }
+}
+
+template <int Q, int POOL>
+__global__ __launch_bounds__(256) void from_image_dx_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                            float* __restrict__ gx, int B, int H, int W, int Ncol, int C) {
+    const long npix = (long)B * H * W;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long pix = gid / Q;
+    const int sub = (int)(gid % Q);
+    const bool ok = pix < npix;
+    const float4 gv = ok ? ld4(g + pix * C + sub * 4) : f4zero();
+    const int xx = (int)(pix % W);
+    const int yy = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    for (int k = 0; k < Ncol; ++k) {
+        const int c0 = sub * 4;
+        float part = gv.x * w[(c0 + 0) * Ncol + k] + gv.y * w[(c0 + 1) * Ncol + k] + gv.z * w[(c0 + 2) * Ncol + k] +
+                     gv.w * w[(c0 + 3) * Ncol + k];
+        const float s = group_sum<Q>(part);
+        if (ok && sub == 0) {
+            if (POOL == 0) {
+                gx[pix * Ncol + k] = s;
+            } else {
+                const long W2 = 2L * W;
+                float* p = gx + (((long)b * 2 * H + 2 * yy) * W2 + 2 * xx) * Ncol + k;
+                const float q4 = 0.25f * s;
+                p[0] = q4; p[Ncol] = q4; p[W2 * Ncol] = q4; p[W2 * Ncol + Ncol] = q4;
+            }
+        }
+    }
+}
+
+// partial slab per block: [c*Ncol + k] for k < Ncol, then [C*Ncol + c] for the bias sums
+template <int Q, int POOL>
+__global__ __launch_bounds__(256) void from_image_dw_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            float* __restrict__ partial, int B, int H, int W, int Ncol, int C) {
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x, sub = tid % Q;
+    const long npix = (long)B * H * W;
+    const long stride = (long)gridDim.x * (256 / Q);
+    float4 acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] = f4zero();
+    for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) {
+        const float4 gv = ld4(g + pix * C + sub * 4);
+        const int xx = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        const int b = (int)(pix / ((long)W * H));
+        acc[4] = f4add(acc[4], gv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < Ncol) acc[k] = f4fma(gv, load_img<POOL>(x, b, yy, xx, k, H, W, Ncol), acc[k]);
+    }
+    float* slab = partial + (long)blockIdx.x * C * (Ncol + 1);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (k < Ncol || k == 4) {
+            float4 s = block_quad_sum<Q>(acc[k], red);
+            if (tid < Q) {
+                const int c0 = tid * 4;
+                if (k == 4) st4(slab + C * Ncol + c0, s);
+                else { slab[(c0 + 0) * Ncol + k] = s.x; slab[(c0 + 1) * Ncol + k] = s.y; slab[(c0 + 2) * Ncol + k] = s.z; slab[(c0 + 3) * Ncol + k] = s.w; }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// ToImage
+// ------------------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(256) void to_image_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ t, long npix, int C, int Ncol) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long pix = gid / Q;
+    const int sub = (int)(gid % Q);
+    const bool ok = pix < npix;
+    const float4 xv = ok ? ld4(x + pix * C + sub * 4) : f4zero();
+    for (int k = 0; k < Ncol; ++k) {
+        const float s = group_sum<Q>(f4dot(xv, ld4(w + k * C + sub * 4)));
+        if (ok && sub == 0) t[pix * Ncol + k] = tanhf(s);
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restrict__ g, const float* __restrict__ t,
+                                                           const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ gx, float* __restrict__ partial,
+                                                           long npix, int C, int Ncol) {
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x, sub = tid % Q;
+    const long stride = (long)gridDim.x * (256 / Q);
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = f4zero();
+    float4 wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[k] = k < Ncol ? ld4(w + k * C + sub * 4) : f4zero();
+    for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) {
+        const float4 xv = ld4(x + pix * C + sub * 4);
+        float4 o = f4zero();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < Ncol) {
+                const float tv = t[pix * Ncol + k];
+                const float qv = g[pix * Ncol + k] * (1.0f - tv * tv);
+                o = f4fma(wv[k], qv, o);
+                acc[k] = f4fma(xv, qv, acc[k]);
+            }
+        st4(gx + pix * C + sub * 4, o);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < Ncol) {
+            float4 s = block_quad_sum<Q>(acc[k], red);
+            if (tid < Q) st4(partial + (long)blockIdx.x * C * Ncol + k * C + tid * 4, s);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// resampling (scalar per element; used on colour images and on feature maps outside fused convs)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C) {
+    const long total = (long)B * 4 * h * w * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int X = (int)(r % (2 * w)); r /= (2 * w);
+        const int Y = (int)(r % (2 * h));
+        const int b = (int)(r / (2 * h));
+        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+        up2_taps(Y, h, y0, y1, wy0, wy1);
+        up2_taps(X, w, x0, x1, wx0, wx1);
+        const float* r0 = x + ((long)b * h + y0) * w * C + c;
+        const float* r1 = x + ((long)b * h + y1) * w * C + c;
+        const float top = fmaf(r0[(long)x1 * C], wx1, r0[(long)x0 * C] * wx0);
+        const float bot = fmaf(r1[(long)x1 * C], wx1, r1[(long)x0 * C] * wx0);
+        y[i] = fmaf(bot, wy1, top * wy0);
+    }
+}
+
+// weight with which low-res index i receives from high-res index R (R in 2i-1 .. 2i+2), n = low-res extent
+__device__ __forceinline__ float up2_adj_w(int i, int R, int n) {
+    if (R < 0 || R > 2 * n - 1) return 0.f;
+    const int d = R - 2 * i;
+    if (d == -1 || d == 2) return 0.25f;
+    if (d == 0) return i == 0 ? 1.0f : 0.75f;
+    return i == n - 1 ? 1.0f : 0.75f;  // d == 1
+}
+
+__global__ void up2_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int h, int w, int C) {
+    const long total = (long)B * h * w * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int X = (int)(r % w); r /= w;
+        const int Y = (int)(r % h);
+        const int b = (int)(r / h);
+        float s = 0.f;
+        for (int dy = -1; dy <= 2; ++dy) {
+            const int RY = 2 * Y + dy;
+            const float wy = up2_adj_w(Y, RY, h);
+            if (wy == 0.f) continue;
+            for (int dx = -1; dx <= 2; ++dx) {
+                const int RX = 2 * X + dx;
+                const float wx = up2_adj_w(X, RX, w);
+                if (wx == 0.f) continue;
+                s = fmaf(wy * wx, gy[(((long)b * 2 * h + RY) * (2 * w) + RX) * C + c], s);
+            }
+        }
+        gx[i] = s;
+    }
+}
+
+__global__ void pool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C) {
+    const long total = (long)B * h * w * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int X = (int)(r % w); r /= w;
+        const int Y = (int)(r % h);
+        const int b = (int)(r / h);
+        const long W2 = 2L * w;
+        const float* p = x + (((long)b * 2 * h + 2 * Y) * W2 + 2 * X) * C + c;
+        y[i] = 0.25f * ((p[0] + p[C]) + (p[W2 * C] + p[W2 * C + C]));
+    }
+}
+
+__global__ void pool2_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int h, int w, int C) {
+    const long total = (long)B * 4 * h * w * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int X = (int)(r % (2 * w)); r /= (2 * w);
+        const int Y = (int)(r % (2 * h));
+        const int b = (int)(r / (2 * h));
+        gx[i] = 0.25f * gy[(((long)b * h + (Y >> 1)) * w + (X >> 1)) * C + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// elementwise arithmetic
+// ------------------------------------------------------------------------------------------------------------
+__global__ void lerp_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ alpha,
+                            float* __restrict__ out, long n) {
+    const float al = alpha[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = fmaf(al, b[i] - a[i], a[i]);
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float ca, float cb,
+                             float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = b ? fmaf(cb, b[i], ca * a[i]) : ca * a[i];
+}
+
+__global__ void fade_bwd_kernel(const float* __restrict__ g, const float* __restrict__ alpha, float* __restrict__ ga,
+                                float* __restrict__ gb, long n) {
+    const float al = alpha[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        ga[i] = (1.0f - al) * v;
+        gb[i] = al * v;
+    }
+}
+
+__global__ void xhat_kernel(const float* __restrict__ real, const float* __restrict__ fake, const float* __restrict__ eps,
+                            float* __restrict__ out, long n) {
+    const int b = blockIdx.y;
+    const float e = eps[b];
+    const long base = (long)b * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[base + i] = e * real[base + i] + (1.0f - e) * fake[base + i];
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ coef, float* __restrict__ out, long n) {
+    const int b = blockIdx.y;
+    const float c = coef[b];
+    const long base = (long)b * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[base + i] = c * g[base + i];
+}
+
+__global__ __launch_bounds__(1024) void sample_l2norm_kernel(const float* __restrict__ g, float* __restrict__ norms, long n) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = g + (long)b * n;
+    float s = 0.f;
+    for (long i = tid; i < n; i += 1024) s = fmaf(p[i], p[i], s);
+    s = group_sum<64>(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        norms[b] = sqrtf(t);
+    }
+}
+
+int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 4096 ? (b < 1 ? 1 : b) : 4096);
+}
+
+#define Q_DISPATCH(CALL)                       \
+    switch (C / 4) {                           \
+        case 1: CALL(1); break;                \
+        case 2: CALL(2); break;                \
+        case 4: CALL(4); break;                \
+        case 8: CALL(8); break;                \
+        case 16: CALL(16); break;              \
+        case 32: CALL(32); break;              \
+        default: CALL(64); break;              \
+    }
+
+}  // namespace
+
+extern "C" int ngan_channel_sum(const float* g, float* out, float* workspace, long npix, int C, float scale, void* stream) {
+    NGAN_REQUIRE(g && out && workspace, NGAN_ERR_ARG, "channel_sum: null pointer");
+    NGAN_REQUIRE(npix > 0 && pow2_quads(C), NGAN_ERR_SHAPE, "channel_sum: npix=%ld C=%d unsupported", npix, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = stream_blocks(npix, C / 4);
+#define CALL(QV) hipLaunchKernelGGL((channel_sum_kernel<QV>), dim3(nblk), dim3(256), 0, s, g, workspace, npix, C)
+    Q_DISPATCH(CALL)
+#undef CALL
+    int st = ngan::launch_status("ngan_channel_sum");
+    if (st) return st;
+    return ngan::reduce_partials(workspace, nblk, C, out, scale, s);
+}
+
+extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int Ncol,
+                                   int C, int pool, void* stream) {
+    NGAN_REQUIRE(x && w && y, NGAN_ERR_ARG, "from_image_fwd: null pointer");
+    NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0, NGAN_ERR_SHAPE,
+                 "from_image_fwd: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ew_blocks((long)B * H * W * (C / 4));
+    if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<1>), dim3(nblk), dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    else hipLaunchKernelGGL((from_image_fwd_kernel<0>), dim3(nblk), dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    return ngan::launch_status("ngan_from_image_fwd");
+}
+
+extern "C" int ngan_from_image_dx(const float* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool,
+                                  void* stream) {
+    NGAN_REQUIRE(g && w && gx, NGAN_ERR_ARG, "from_image_dx: null pointer");
+    NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
+                 "from_image_dx: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ceil_div((long)B * H * W * (C / 4), 256);
+#define CALL(QV)                                                                                                     \
+    if (pool) hipLaunchKernelGGL((from_image_dx_kernel<QV, 1>), dim3(nblk), dim3(256), 0, s, g, w, gx, B, H, W, Ncol, C); \
+    else hipLaunchKernelGGL((from_image_dx_kernel<QV, 0>), dim3(nblk), dim3(256), 0, s, g, w, gx, B, H, W, Ncol, C)
+    Q_DISPATCH(CALL)
+#undef CALL
+    return ngan::launch_status("ngan_from_image_dx");
+}
+
+extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
+                                  int Ncol, int C, int pool, void* stream) {
+    NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "from_image_dw: null pointer");
+    NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
+                 "from_image_dw: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = stream_blocks((long)B * H * W, C / 4);
+#define CALL(QV)                                                                                                              \
+    if (pool) hipLaunchKernelGGL((from_image_dw_kernel<QV, 1>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C); \
+    else hipLaunchKernelGGL((from_image_dw_kernel<QV, 0>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C)
+    Q_DISPATCH(CALL)
+#undef CALL
+    int st = ngan::launch_status("ngan_from_image_dw");
+    if (st) return st;
+    const long stride = (long)C * (Ncol + 1);
+    st = ngan::reduce_partials_strided(workspace, nblk, C * Ncol, stride, gw, 1.0f, s);
+    if (st || !gb) return st;
+    return ngan::reduce_partials_strided(workspace + (long)C * Ncol, nblk, C, stride, gb, 1.0f, s);
+}
+
+extern "C" int ngan_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, void* stream) {
+    NGAN_REQUIRE(x && w && t, NGAN_ERR_ARG, "to_image_fwd: null pointer");
+    NGAN_REQUIRE(npix > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE, "to_image_fwd: npix=%ld C=%d Ncol=%d unsupported",
+                 npix, C, Ncol);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ceil_div(npix * (C / 4), 256);
+#define CALL(QV) hipLaunchKernelGGL((to_image_fwd_kernel<QV>), dim3(nblk), dim3(256), 0, s, x, w, t, npix, C, Ncol)
+    Q_DISPATCH(CALL)
+#undef CALL
+    return ngan::launch_status("ngan_to_image_fwd");
+}
+
+extern "C" int ngan_to_image_bwd(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
+                                 float* workspace, long npix, int C, int Ncol, void* stream) {
+    NGAN_REQUIRE(g && t && x && w && gx && gw && workspace, NGAN_ERR_ARG, "to_image_bwd: null pointer");
+    NGAN_REQUIRE(npix > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE, "to_image_bwd: npix=%ld C=%d Ncol=%d unsupported",
+                 npix, C, Ncol);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = stream_blocks(npix, C / 4);
+#define CALL(QV) hipLaunchKernelGGL((to_image_bwd_kernel<QV>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol)
+    Q_DISPATCH(CALL)
+#undef CALL
+    int st = ngan::launch_status("ngan_to_image_bwd");
+    if (st) return st;
+    return ngan::reduce_partials(workspace, nblk, C * Ncol, gw, 1.0f, s);
+}
+
+#define RESAMPLE_API(NAME, KERNEL, TOTAL)                                                                      \
+    extern "C" int NAME(const float* a, float* o, int B, int h, int w, int C, void* stream) {                   \
+        NGAN_REQUIRE(a && o, NGAN_ERR_ARG, #NAME ": null pointer");                                            \
+        NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, #NAME ": bad dims %d %d %d %d", B, h, w, C); \
+        hipLaunchKernelGGL(KERNEL, dim3(ew_blocks(TOTAL)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);  \
+        return ngan::launch_status(#NAME);                                                                     \
+    }
+RESAMPLE_API(ngan_up2_fwd, up2_fwd_kernel, (long)B * 4 * h * w * C)
+RESAMPLE_API(ngan_up2_adjoint, up2_adjoint_kernel, (long)B * h * w * C)
+RESAMPLE_API(ngan_pool2_fwd, pool2_fwd_kernel, (long)B * h * w * C)
+RESAMPLE_API(ngan_pool2_adjoint, pool2_adjoint_kernel, (long)B * 4 * h * w * C)
+
+extern "C" int ngan_lerp(const float* a, const float* b, const float* alpha, float* out, long n, void* stream) {
+    NGAN_REQUIRE(a && b && alpha && out && n > 0, NGAN_ERR_ARG, "lerp: bad argument");
+    hipLaunchKernelGGL(lerp_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, out, n);
+    return ngan::launch_status("ngan_lerp");
+}
+
+extern "C" int ngan_axpby(const float* a, const float* b, float ca, float cb, float* out, long n, void* stream) {
+    NGAN_REQUIRE(a && out && n > 0, NGAN_ERR_ARG, "axpby: bad argument");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, ca, cb, out, n);
+    return ngan::launch_status("ngan_axpby");
+}
+
+extern "C" int ngan_fade_bwd(const float* g, const float* alpha, float* ga, float* gb, long n, void* stream) {
+    NGAN_REQUIRE(g && alpha && ga && gb && n > 0, NGAN_ERR_ARG, "fade_bwd: bad argument");
+    hipLaunchKernelGGL(fade_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, alpha, ga, gb, n);
+    return ngan::launch_status("ngan_fade_bwd");
+}
+
+extern "C" int ngan_xhat(const float* real, const float* fake, const float* eps, float* out, int B, long n, void* stream) {
+    NGAN_REQUIRE(real && fake && eps && out && B > 0 && n > 0, NGAN_ERR_ARG, "xhat: bad argument");
+    int bx = ew_blocks(n);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(xhat_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, real, fake, eps, out, n);
+    return ngan::launch_status("ngan_xhat");
+}
+
+extern "C" int ngan_scale_rows(const float* g, const float* coef, float* out, int B, long n, void* stream) {
+    NGAN_REQUIRE(g && coef && out && B > 0 && n > 0, NGAN_ERR_ARG, "scale_rows: bad argument");
+    int bx = ew_blocks(n);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, g, coef, out, n);
+    return ngan::launch_status("ngan_scale_rows");
+}
+
+extern "C" int ngan_sample_l2norm(const float* g, float* norms, int B, long n, void* stream) {
+    NGAN_REQUIRE(g && norms && B > 0 && n > 0, NGAN_ERR_ARG, "sample_l2norm: bad argument");
+    hipLaunchKernelGGL(sample_l2norm_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, g, norms, n);
+    return ngan::launch_status("ngan_sample_l2norm");
+}

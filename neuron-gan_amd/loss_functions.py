@@ -1,0 +1,92 @@
+"""WGAN / WGAN-GP losses with the reference's interface (loss_functions.py:7-74, 148-180), running on the HIP ops.
+
+    D_W_loss(G, D, drift_epsilon)(real)      -> (loss, score_real, score_fake)
+    G_W_loss(G, D)(real)                     -> (loss, z)
+    D_grad_pen_loss(G, D, Lambda)(real)      -> loss   (create_graph double-backward through the critic)
+
+Latents come from `utils.sample_latent_vec` unless a tensor is passed through the optional `z=` / `epsilon=`
+keywords (how the parity tests inject the reference's draws).  NaN handling: the reference dumps locals and
+raises `ValueError` (loss_functions.py:35-41, 70-72); here the check is optional (`check_nan`) because
+`torch.isnan(...)` in an `if` is a host sync on the GPU -- the training loop checks once per epoch instead.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .utils import sample_latent_vec
+
+
+def _latents(net, batch, device, z):
+    if z is not None:
+        return z
+    return sample_latent_vec((batch, net.latent_dim), device=device)
+
+
+class D_W_loss(nn.Module):
+    def __init__(self, generator_net, discriminator_net, drift_epsilon=0.0, check_nan=True):
+        super().__init__()
+        self.generator_net = generator_net
+        self.discriminator_net = discriminator_net
+        self.drift_epsilon = drift_epsilon
+        self.check_nan = check_nan
+
+    def forward(self, real_images, z=None):
+        batch_size, device = real_images.size(0), real_images.device
+        real_images_score = self.discriminator_net(real_images)
+        score_real = real_images_score.mean()
+        z = _latents(self.generator_net, batch_size, device, z)
+        with torch.no_grad():
+            fake_images = self.generator_net(z)
+        score_fake = self.discriminator_net(fake_images).mean()
+        D_loss = -score_real + score_fake
+        if self.check_nan:
+            if torch.isnan(score_real):
+                raise ValueError('Real loss is nan.')
+            if torch.isnan(score_fake):
+                raise ValueError('Fake loss is nan.')
+        if self.drift_epsilon > 0:
+            D_loss = D_loss + self.drift_epsilon * torch.square(real_images_score).mean()
+        return D_loss, score_real, score_fake
+
+
+class G_W_loss(nn.Module):
+    def __init__(self, generator_net, discriminator_net, check_nan=True):
+        super().__init__()
+        self.generator_net = generator_net
+        self.discriminator_net = discriminator_net
+        self.check_nan = check_nan
+
+    def forward(self, real_images_batch, z=None):
+        batch_size, device = real_images_batch.size(0), real_images_batch.device
+        z_latent = _latents(self.generator_net, batch_size, device, z)
+        fake_images = self.generator_net(z_latent)
+        G_loss = -self.discriminator_net(fake_images).mean()
+        if self.check_nan and torch.isnan(G_loss):
+            raise ValueError('Generator loss is nan.')
+        return G_loss, z_latent
+
+
+class D_grad_pen_loss(nn.Module):
+    def __init__(self, generator_net, discriminator_net, Lambda):
+        super().__init__()
+        self.generator_net = generator_net
+        self.discriminator_net = discriminator_net
+        self.Lambda = Lambda
+        self.last_grad_norms = None  # per-sample |grad D| of the last call (monitoring / parity tests)
+
+    def forward(self, real_images, z=None, epsilon=None):
+        if not self.Lambda > 0:
+            return torch.tensor(0)
+        batch_size, device = real_images.size(0), real_images.device
+        z_latent = _latents(self.generator_net, batch_size, device, z)
+        with torch.no_grad():
+            x_tilde = self.generator_net(z_latent)
+        if epsilon is None:
+            epsilon = torch.rand((batch_size, 1, 1, 1), device=device)
+        x_hat = ops.xhat(real_images, x_tilde, epsilon)
+        x_hat.requires_grad_()
+        output = self.discriminator_net(x_hat)
+        Disc_grad = torch.autograd.grad(outputs=output.sum(), inputs=x_hat, create_graph=True)[0]
+        norms = ops.SampleL2Norm.apply(Disc_grad)
+        self.last_grad_norms = norms.detach()
+        return self.Lambda * torch.mean((norms - 1) ** 2)

@@ -1,0 +1,650 @@
+"""Differentiable operators of the PGGAN / WGAN-GP hot path, each backed by hand-written gfx950 kernels
+(include/ngan.h) and closed under differentiation, so that the gradient-penalty double-backward through the
+critic (loss_functions.py:175 in the reference) runs entirely on those kernels.
+
+All tensors here are fp32, contiguous, channels-last: (B, H, W, C).  `models.py` converts at the module edges.
+
+Closure under differentiation (what the backward of each operator is built from):
+    ConvLReLUPN   -> LReLUPNBwd, ConvDgrad, ConvWgrad, ChannelSum
+    Conv          -> ConvDgrad, ConvWgrad, ChannelSum
+    ConvDgrad     -> Conv, ConvWgrad                 ConvWgrad -> ConvDgrad, Conv
+    LReLUPNBwd    -> lrelu_pixelnorm_bwdbwd (the only operator with a non-zero Hessian)
+    FromImage / FromImageDx / FromImageDw, FinalDot / FinalDotDx / FinalDotDw: bilinear triples, closed
+    Lerp <-> FadeBwd, Up2 <-> Up2Adjoint, Pool2 <-> Pool2Adjoint: linear pairs
+"""
+import weakref
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _C
+
+RES_NONE, RES_POOL2, RES_UP2 = 0, 1, 2
+PIXELNORM_EPS = 1e-8  # models.py:105 of the reference
+
+# ---------------------------------------------------------------------------------------------------------
+# packed-weight cache.  Packed (MFMA fragment order, pre-scaled) copies are valid for one "weight epoch":
+# the optimiser updates parameters through raw pointers, so it must call bump_weight_epoch() afterwards.
+# ---------------------------------------------------------------------------------------------------------
+_weight_epoch = 0
+_pack_cache = {}
+
+
+def bump_weight_epoch():
+    global _weight_epoch
+    _weight_epoch += 1
+    _pack_cache.clear()
+
+
+def _packed(weight, mode, scale):
+    # identity is checked through a weak reference: a data_ptr alone can be recycled by the allocator
+    key = (id(weight), weight.data_ptr(), weight._version, mode, float(scale), _weight_epoch)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight:
+        return hit[1]
+    cout, cin = weight.shape[0], weight.shape[1]
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    packed = torch.empty(9 * cin * cout, device=weight.device, dtype=torch.float32)
+    _C.call("ngan_conv3x3_pack_weights", w, packed, cout, cin, mode, float(scale))
+    _pack_cache[key] = (weakref.ref(weight), packed)
+    return packed
+
+
+def _c(t):
+    """contiguous fp32 view of a gradient tensor (autograd may hand us expanded / non-contiguous grads)"""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"the HIP path computes in fp32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _conv_in_shape(out_shape_bhw, resample):
+    b, h, w = out_shape_bhw
+    if resample == RES_POOL2:
+        return b, 2 * h, 2 * w
+    if resample == RES_UP2:
+        return b, h // 2, w // 2
+    return b, h, w
+
+
+def _conv_out_hw(x, resample):
+    b, h, w, _ = x.shape
+    if resample == RES_POOL2:
+        return b, h // 2, w // 2
+    if resample == RES_UP2:
+        return b, 2 * h, 2 * w
+    return b, h, w
+
+
+def _run_conv(x, weight, bias, resample, scale, epilogue, slope):
+    """y (and rnorm) = epilogue(conv3x3(resample(x), scale*W) + bias)"""
+    b, h, w = _conv_out_hw(x, resample)
+    cout, cin = weight.shape[0], weight.shape[1]
+    if x.shape[3] != cin:
+        raise RuntimeError(f"conv3x3: input has {x.shape[3]} channels, weight expects {cin}")
+    y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32)
+    rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if epilogue else None
+    _C.call("ngan_conv3x3_fwd", x, _packed(weight, 0, scale), bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0,
+            float(slope), PIXELNORM_EPS)
+    return y, rn
+
+
+def _run_dgrad(g, weight, resample, scale):
+    """gx = resample^T(conv3x3_transposed(g, scale*W))"""
+    b, h, w, cout = g.shape
+    cin = weight.shape[1]
+    if cout != weight.shape[0]:
+        raise RuntimeError(f"conv3x3 dgrad: gradient has {cout} channels, weight has {weight.shape[0]} outputs")
+    packed = _packed(weight, 1, scale)
+    if resample == RES_POOL2:
+        gx = torch.empty((b, 2 * h, 2 * w, cin), device=g.device, dtype=torch.float32)
+        _C.call("ngan_conv3x3_fwd", g, packed, None, gx, None, b, h, w, cout, cin, 0, 0, 1, 0.0, 0.0)
+        return gx
+    gfull = torch.empty((b, h, w, cin), device=g.device, dtype=torch.float32)
+    _C.call("ngan_conv3x3_fwd", g, packed, None, gfull, None, b, h, w, cout, cin, 0, 0, 0, 0.0, 0.0)
+    if resample == RES_UP2:
+        gx = torch.empty((b, h // 2, w // 2, cin), device=g.device, dtype=torch.float32)
+        _C.call("ngan_up2_adjoint", gfull, gx, b, h // 2, w // 2, cin)
+        return gx
+    return gfull
+
+
+def _run_wgrad(x, g, resample, scale):
+    b, h, w, cout = g.shape
+    cin = x.shape[3]
+    gw = torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
+    ws = torch.empty(_C.wgrad_workspace_bytes(b, h, w, cin, cout) // 4, device=g.device, dtype=torch.float32)
+    _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale))
+    return gw
+
+
+def _channel_sum(g):
+    c = g.shape[-1]
+    npix = g.numel() // c
+    out = torch.empty(c, device=g.device, dtype=torch.float32)
+    ws = torch.empty(1024 * c, device=g.device, dtype=torch.float32)
+    _C.call("ngan_channel_sum", g, out, ws, npix, c, 1.0)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3x3 convolution family
+# ---------------------------------------------------------------------------------------------------------
+class ConvLReLUPN(Function):
+    """(y, rnorm) = PixelNorm(LeakyReLU(conv3x3(resample(x), scale*W) + bias)): one fused kernel forward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, resample, scale, slope):
+        ctx.set_materialize_grads(False)
+        x = _c(x)
+        y, rn = _run_conv(x, weight, bias, resample, scale, 1, slope)
+        ctx.save_for_backward(x, weight, y, rn)
+        ctx.has_bias = bias is not None
+        ctx.cfg = (resample, scale, slope)
+        return y, rn
+
+    @staticmethod
+    def backward(ctx, gy, gr):
+        x, weight, y, rn = ctx.saved_tensors
+        resample, scale, slope = ctx.cfg
+        if gy is None and gr is None:
+            return None, None, None, None, None, None
+        if gy is None:
+            gy = torch.zeros_like(y)
+        gc = LReLUPNBwd.apply(gy, gr, y, rn, slope)
+        gx = ConvDgrad.apply(gc, weight, resample, scale) if ctx.needs_input_grad[0] else None
+        gw = ConvWgrad.apply(x, gc, resample, scale) if ctx.needs_input_grad[1] else None
+        gb = ChannelSum.apply(gc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None
+
+
+class Conv(Function):
+    """c = conv3x3(resample(x), scale*W) + bias, no activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, resample, scale):
+        x = _c(x)
+        y, _ = _run_conv(x, weight, bias, resample, scale, 0, 0.0)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.cfg = (resample, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        resample, scale = ctx.cfg
+        gx = ConvDgrad.apply(g, weight, resample, scale) if ctx.needs_input_grad[0] else None
+        gw = ConvWgrad.apply(x, g, resample, scale) if ctx.needs_input_grad[1] else None
+        gb = ChannelSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None
+
+
+class ConvDgrad(Function):
+    """gx = resample^T(conv3x3^T(g, scale*W)); linear in g and in W."""
+
+    @staticmethod
+    def forward(ctx, g, weight, resample, scale):
+        g = _c(g)
+        ctx.save_for_backward(g, weight)
+        ctx.cfg = (resample, scale)
+        return _run_dgrad(g, weight, resample, scale)
+
+    @staticmethod
+    def backward(ctx, h):
+        g, weight = ctx.saved_tensors
+        resample, scale = ctx.cfg
+        gg = Conv.apply(h, weight, None, resample, scale) if ctx.needs_input_grad[0] else None
+        gw = ConvWgrad.apply(h, g, resample, scale) if ctx.needs_input_grad[1] else None
+        return gg, gw, None, None
+
+
+class ConvWgrad(Function):
+    """gW (OIHW) = scale * sum_pixels g (x) resample(x); linear in x and in g."""
+
+    @staticmethod
+    def forward(ctx, x, g, resample, scale):
+        x, g = _c(x), _c(g)
+        ctx.save_for_backward(x, g)
+        ctx.cfg = (resample, scale)
+        return _run_wgrad(x, g, resample, scale)
+
+    @staticmethod
+    def backward(ctx, hw):
+        x, g = ctx.saved_tensors
+        resample, scale = ctx.cfg
+        hw = _c(hw)
+        gx = ConvDgrad.apply(g, hw, resample, scale) if ctx.needs_input_grad[0] else None
+        gg = Conv.apply(x, hw, None, resample, scale) if ctx.needs_input_grad[1] else None
+        return gx, gg, None, None
+
+
+class ChannelSum(Function):
+    """out[c] = sum over pixels of g[..., c] (bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = _c(g)
+        ctx.shape = g.shape
+        return _channel_sum(g)
+
+    @staticmethod
+    def backward(ctx, h):
+        return h.expand(ctx.shape)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LeakyReLU -> PixelNorm
+# ---------------------------------------------------------------------------------------------------------
+class LReLUPN(Function):
+    """(y, rnorm) = PixelNorm(LeakyReLU(c + bias)) as a standalone kernel."""
+
+    @staticmethod
+    def forward(ctx, c, bias, slope):
+        ctx.set_materialize_grads(False)
+        c = _c(c)
+        ch = c.shape[-1]
+        y = torch.empty_like(c)
+        rn = torch.empty(c.shape[:-1], device=c.device, dtype=torch.float32)
+        _C.call("ngan_lrelu_pixelnorm_fwd", c, bias, y, rn, c.numel() // ch, ch, float(slope), PIXELNORM_EPS)
+        ctx.save_for_backward(y, rn)
+        ctx.slope = slope
+        ctx.has_bias = bias is not None
+        return y, rn
+
+    @staticmethod
+    def backward(ctx, gy, gr):
+        y, rn = ctx.saved_tensors
+        if gy is None and gr is None:
+            return None, None, None
+        if gy is None:
+            gy = torch.zeros_like(y)
+        gc = LReLUPNBwd.apply(gy, gr, y, rn, ctx.slope)
+        gb = ChannelSum.apply(gc) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return gc, gb, None
+
+
+class LReLUPNBwd(Function):
+    """gc = m * ((gy - y*mean_c(gy*y))/r + gr*y/C): first-order backward of LeakyReLU->PixelNorm."""
+
+    @staticmethod
+    def forward(ctx, gy, gr, y, rn, slope):
+        gy, gr = _c(gy), _c(gr)
+        ch = y.shape[-1]
+        gc = torch.empty_like(y)
+        _C.call("ngan_lrelu_pixelnorm_bwd", gy, gr, y, rn, gc, y.numel() // ch, ch, float(slope))
+        ctx.save_for_backward(gy, y, rn)
+        ctx.had_gr = gr is not None
+        ctx.slope = slope
+        return gc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h):
+        if ctx.had_gr:
+            raise NotImplementedError("third-order derivative through LeakyReLU->PixelNorm is not on the WGAN-GP path")
+        gy, y, rn = ctx.saved_tensors
+        h = _c(h)
+        ch = y.shape[-1]
+        ggy = torch.empty_like(y)
+        gy_out = torch.empty_like(y)
+        gr_out = torch.empty_like(rn)
+        _C.call("ngan_lrelu_pixelnorm_bwdbwd", h, gy, y, rn, ggy, gy_out, gr_out, y.numel() // ch, ch, float(ctx.slope))
+        return ggy, None, gy_out, gr_out, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# FromImage (1x1 conv from colour space, + bias), optional avg-pool on load for the fade-in branch
+# ---------------------------------------------------------------------------------------------------------
+def _from_image_out_hw(x, pool):
+    b, h, w, _ = x.shape
+    return (b, h // 2, w // 2) if pool else (b, h, w)
+
+
+class FromImage(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, pool):
+        x = _c(x)
+        b, h, wd = _from_image_out_hw(x, pool)
+        c, ncol = w.shape[0], w.shape[1]
+        y = torch.empty((b, h, wd, c), device=x.device, dtype=torch.float32)
+        _C.call("ngan_from_image_fwd", x, w.detach().reshape(c, ncol), bias, y, b, h, wd, ncol, c, int(pool))
+        ctx.save_for_backward(x, w)
+        ctx.pool = pool
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = FromImageDx.apply(g, w, ctx.pool) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = FromImageDw.apply(x, g, ctx.pool, tuple(w.shape))
+            if not ctx.has_bias:
+                gb = None
+        return gx, gw, gb, None
+
+
+class FromImageDx(Function):
+    @staticmethod
+    def forward(ctx, g, w, pool):
+        g = _c(g)
+        b, h, wd, c = g.shape
+        ncol = w.shape[1]
+        gx = torch.empty((b, 2 * h, 2 * wd, ncol) if pool else (b, h, wd, ncol), device=g.device, dtype=torch.float32)
+        _C.call("ngan_from_image_dx", g, w.detach().reshape(c, ncol), gx, b, h, wd, ncol, c, int(pool))
+        ctx.save_for_backward(g, w)
+        ctx.pool = pool
+        return gx
+
+    @staticmethod
+    def backward(ctx, h):
+        g, w = ctx.saved_tensors
+        gg = FromImage.apply(h, w, None, ctx.pool) if ctx.needs_input_grad[0] else None
+        gw = FromImageDw.apply(h, g, ctx.pool, tuple(w.shape))[0] if ctx.needs_input_grad[1] else None
+        return gg, gw, None
+
+
+class FromImageDw(Function):
+    @staticmethod
+    def forward(ctx, x, g, pool, w_shape):
+        x, g = _c(x), _c(g)
+        b, h, wd, c = g.shape
+        ncol = x.shape[3]
+        gw = torch.empty(w_shape, device=g.device, dtype=torch.float32)
+        gb = torch.empty(c, device=g.device, dtype=torch.float32)
+        ws = torch.empty(1024 * c * (ncol + 1), device=g.device, dtype=torch.float32)
+        _C.call("ngan_from_image_dw", x, g, gw, gb, ws, b, h, wd, ncol, c, int(pool))
+        ctx.save_for_backward(x, g)
+        ctx.pool = pool
+        return gw, gb
+
+    @staticmethod
+    def backward(ctx, hw, hb):
+        x, g = ctx.saved_tensors
+        gx = gg = None
+        if hw is not None:
+            hw = _c(hw)
+            if ctx.needs_input_grad[0]:
+                gx = FromImageDx.apply(g, hw, ctx.pool)
+            if ctx.needs_input_grad[1]:
+                gg = FromImage.apply(x, hw, _c(hb), ctx.pool)
+        elif hb is not None and ctx.needs_input_grad[1]:
+            gg = hb.expand(g.shape)
+        return gx, gg, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ToImage (1x1 conv to colour space + tanh): generator only, first order
+# ---------------------------------------------------------------------------------------------------------
+class ToImage(Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _c(x)
+        ncol, c = w.shape[0], w.shape[1]
+        t = torch.empty(x.shape[:-1] + (ncol,), device=x.device, dtype=torch.float32)
+        _C.call("ngan_to_image_fwd", x, w.detach().reshape(ncol, c), t, x.numel() // c, c, ncol)
+        ctx.save_for_backward(x, w, t)
+        return t
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w, t = ctx.saved_tensors
+        g = _c(g)
+        ncol, c = w.shape[0], w.shape[1]
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(w)
+        ws = torch.empty(1024 * c * ncol, device=x.device, dtype=torch.float32)
+        _C.call("ngan_to_image_bwd", g, t, x, w.detach().reshape(ncol, c), gx, gw, ws, x.numel() // c, c, ncol)
+        return gx, gw
+
+
+# ---------------------------------------------------------------------------------------------------------
+# resampling and fade-in (linear pairs)
+# ---------------------------------------------------------------------------------------------------------
+def _resample(name, x, out_shape, b, h, w, c):
+    out = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+    _C.call(name, x, out, b, h, w, c)
+    return out
+
+
+class Up2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        b, h, w, c = x.shape
+        return _resample("ngan_up2_fwd", x, (b, 2 * h, 2 * w, c), b, h, w, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return Up2Adjoint.apply(g)
+
+
+class Up2Adjoint(Function):
+    @staticmethod
+    def forward(ctx, g):
+        g = _c(g)
+        b, h2, w2, c = g.shape
+        return _resample("ngan_up2_adjoint", g, (b, h2 // 2, w2 // 2, c), b, h2 // 2, w2 // 2, c)
+
+    @staticmethod
+    def backward(ctx, h):
+        return Up2.apply(h)
+
+
+class Pool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        b, h2, w2, c = x.shape
+        return _resample("ngan_pool2_fwd", x, (b, h2 // 2, w2 // 2, c), b, h2 // 2, w2 // 2, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return Pool2Adjoint.apply(g)
+
+
+class Pool2Adjoint(Function):
+    @staticmethod
+    def forward(ctx, g):
+        g = _c(g)
+        b, h, w, c = g.shape
+        return _resample("ngan_pool2_adjoint", g, (b, 2 * h, 2 * w, c), b, h, w, c)
+
+    @staticmethod
+    def backward(ctx, h):
+        return Pool2.apply(h)
+
+
+class Lerp(Function):
+    """out = a + alpha*(b - a); alpha is a 1-element device tensor (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        _C.call("ngan_lerp", a, b, alpha, out, a.numel())
+        ctx.save_for_backward(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (alpha,) = ctx.saved_tensors
+        ga, gb = FadeBwd.apply(g, alpha)
+        return ga, gb, None
+
+
+class FadeBwd(Function):
+    @staticmethod
+    def forward(ctx, g, alpha):
+        g = _c(g)
+        ga, gb = torch.empty_like(g), torch.empty_like(g)
+        _C.call("ngan_fade_bwd", g, alpha, ga, gb, g.numel())
+        ctx.save_for_backward(alpha)
+        return ga, gb
+
+    @staticmethod
+    def backward(ctx, ha, hb):
+        (alpha,) = ctx.saved_tensors
+        if ha is None and hb is None:
+            return None, None
+        if ha is None:
+            ha = torch.zeros_like(hb)
+        if hb is None:
+            hb = torch.zeros_like(ha)
+        return Lerp.apply(ha, hb, alpha), None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# generator stem and critic head
+# ---------------------------------------------------------------------------------------------------------
+class LinearLReLUPN(Function):
+    """y (B,S,S,C) = PixelNorm(LeakyReLU(Unflatten(Linear(scale*z, W)))): generator stem, first order."""
+
+    @staticmethod
+    def forward(ctx, z, weight, size, scale, slope):
+        z = _c(z)
+        b, k = z.shape
+        s2 = size * size
+        c = weight.shape[0] // s2
+        y = torch.empty((b, size, size, c), device=z.device, dtype=torch.float32)
+        rn = torch.empty((b, size, size), device=z.device, dtype=torch.float32)
+        _C.call("ngan_linear_lrelu_pn_fwd", z, weight.detach(), y, rn, b, k, s2, c, float(scale), float(slope), PIXELNORM_EPS)
+        ctx.save_for_backward(z, weight, y, rn)
+        ctx.cfg = (s2, c, scale, slope)
+        ctx.mark_non_differentiable(rn)
+        return y, rn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _gr):
+        z, weight, y, rn = ctx.saved_tensors
+        s2, c, scale, slope = ctx.cfg
+        b, k = z.shape
+        gy = _c(gy)
+        gc = torch.empty_like(y)
+        _C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, b * s2, c, float(slope))
+        gz = gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            _C.call("ngan_linear_wgrad", z, gc, gw, b, k, s2, c, float(scale))
+        if ctx.needs_input_grad[0]:
+            gz = torch.empty_like(z)
+            _C.call("ngan_linear_dgrad", gc, weight.detach(), gz, b, k, s2, c, float(scale))
+        return gz, gw, None, None, None
+
+
+class FinalDot(Function):
+    """out (B,1) = scale * <y[b], W> + bias: the critic's full-extent valid conv."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, scale):
+        y = _c(y)
+        b = y.shape[0]
+        c = y.shape[3]
+        s2 = y.shape[1] * y.shape[2]
+        out = torch.empty((b, 1), device=y.device, dtype=torch.float32)
+        _C.call("ngan_final_dot_fwd", y, weight.detach(), bias, out, b, s2, c, float(scale))
+        ctx.save_for_backward(y, weight)
+        ctx.scale = scale
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        y, weight = ctx.saved_tensors
+        gy = FinalDotDx.apply(go, weight, ctx.scale, tuple(y.shape)) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = FinalDotDw.apply(y, go, ctx.scale, tuple(weight.shape))
+            if not ctx.has_bias:
+                gb = None
+        return gy, gw, gb, None
+
+
+class FinalDotDx(Function):
+    @staticmethod
+    def forward(ctx, go, weight, scale, y_shape):
+        go = _c(go)
+        b, h, w, c = y_shape
+        gy = torch.empty(y_shape, device=go.device, dtype=torch.float32)
+        _C.call("ngan_final_dot_dx", go, weight.detach(), gy, b, h * w, c, float(scale))
+        ctx.save_for_backward(go, weight)
+        ctx.scale = scale
+        return gy
+
+    @staticmethod
+    def backward(ctx, h):
+        go, weight = ctx.saved_tensors
+        ggo = FinalDot.apply(h, weight, None, ctx.scale) if ctx.needs_input_grad[0] else None
+        gw = FinalDotDw.apply(h, go, ctx.scale, tuple(weight.shape))[0] if ctx.needs_input_grad[1] else None
+        return ggo, gw, None, None
+
+
+class FinalDotDw(Function):
+    @staticmethod
+    def forward(ctx, y, go, scale, w_shape):
+        y, go = _c(y), _c(go)
+        b, h, w, c = y.shape
+        gw = torch.empty(w_shape, device=y.device, dtype=torch.float32)
+        gb = torch.empty(1, device=y.device, dtype=torch.float32)
+        _C.call("ngan_final_dot_dw", y, go, gw, gb, b, h * w, c, float(scale))
+        ctx.save_for_backward(y, go)
+        ctx.scale = scale
+        return gw, gb
+
+    @staticmethod
+    def backward(ctx, hw, hb):
+        y, go = ctx.saved_tensors
+        gy = ggo = None
+        if hw is not None:
+            hw = _c(hw)
+            if ctx.needs_input_grad[0]:
+                gy = FinalDotDx.apply(go, hw, ctx.scale, tuple(y.shape))
+            if ctx.needs_input_grad[1]:
+                ggo = FinalDot.apply(y, hw, None, ctx.scale)
+        if hb is not None and ctx.needs_input_grad[1]:
+            e = hb.expand(go.shape)
+            ggo = e if ggo is None else ggo + e
+        return gy, ggo, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# gradient-penalty pieces
+# ---------------------------------------------------------------------------------------------------------
+def xhat(real, fake, eps):
+    """x_hat[b] = eps[b]*real[b] + (1-eps[b])*fake[b]  (loss_functions.py:171); inputs carry no gradient."""
+    real, fake = _c(real), _c(fake)
+    b = real.shape[0]
+    out = torch.empty_like(real)
+    _C.call("ngan_xhat", real, fake, _c(eps.reshape(b)), out, b, real.numel() // b)
+    return out
+
+
+class SampleL2Norm(Function):
+    """norms[b] = ||g[b]||_2 over all non-batch dims (loss_functions.py:176)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = _c(g)
+        b = g.shape[0]
+        norms = torch.empty(b, device=g.device, dtype=torch.float32)
+        _C.call("ngan_sample_l2norm", g, norms, b, g.numel() // b)
+        ctx.save_for_backward(g, norms)
+        return norms
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, hn):
+        g, norms = ctx.saved_tensors
+        b = g.shape[0]
+        coef = (hn / norms).contiguous()
+        out = torch.empty_like(g)
+        _C.call("ngan_scale_rows", g, coef, out, b, g.numel() // b)
+        return out

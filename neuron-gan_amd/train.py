@@ -1,0 +1,278 @@
+"""The PGGAN / WGAN-GP training-step driver on MI355X.
+
+Restates the reference's hot loop (/root/reference/train.py:350-394: n_critic x [D loss + gradient penalty, backward,
+Adam], then G loss, backward, Adam) as an engine object instead of module-level script code:
+
+  * every parameter of a net is re-homed into ONE flat fp32 buffer, and every gradient into another, so that
+    zeroing gradients is one memset, the data-parallel exchange is one RCCL all-reduce per net per step, and
+    Adam is one fused kernel launch (`ngan_adam_step`) instead of ~45 ATen foreach chains;
+  * hyper-parameters, step counts and the fade-in alpha live in device memory and latents can be drawn on the
+    GPU, so a whole iteration can be captured into a HIP graph and replayed with no host work;
+  * the critic's parameter gradients that the reference computes and throws away in the G step
+    (train.py:384) are not computed.
+
+The epoch-level semantics (LR schedule train.py:232-265, per-epoch alpha advance and growth train.py:318-333) are
+provided by `lr_schedule` / `PGGANTrainer.start_epoch`; data loading, plotting and checkpoints are out of scope.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _C, ops
+from .loss_functions import D_W_loss, D_grad_pen_loss, G_W_loss
+from .utils import sample_latent_vec, sample_latent_vec_device
+
+ADAM_CHUNK = 4096  # elements per work item of ngan_adam_step (must match csrc/adam.hip)
+SEG_ALIGN = 64     # parameters start on 256-byte boundaries inside the flat buffers
+
+
+class FlatParams:
+    """All parameters of a net as views into one flat buffer (plus flat grad / Adam state buffers)."""
+
+    def __init__(self, net: torch.nn.Module):
+        self.params = list(net.parameters())
+        self.names = [n for n, _ in net.named_parameters()]
+        assert self.params, "network has no parameters"
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatParams needs the network on the GPU (call net.to('cuda') first)")
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + SEG_ALIGN - 1) // SEG_ALIGN * SEG_ALIGN
+        self.offsets, self.total = offs, total
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
+        for p, off in zip(self.params, offs):
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        # device-side tables for ngan_adam_step
+        self.seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.seg_len = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
+        self.seg_active = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
+        self.seg_step = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        cseg, coff = [], []
+        for i, p in enumerate(self.params):
+            for o in range(0, p.numel(), ADAM_CHUNK):
+                cseg.append(i)
+                coff.append(o)
+        self.chunk_seg = torch.tensor(cseg, dtype=torch.int32, device=dev)
+        self.chunk_off = torch.tensor(coff, dtype=torch.int64, device=dev)
+
+    def set_active(self, active_params):
+        """Mark which tensors receive gradients at the current stage (torch's Adam skips .grad=None tensors)."""
+        flags = torch.zeros(len(self.params), dtype=torch.int32)
+        for p in active_params:
+            flags[self.index[id(p)]] = 1
+        self.seg_active.copy_(flags, non_blocking=True)
+        self.active_host = flags.numpy().copy()
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def ensure_grad_views(self):
+        """Re-attach .grad views if something (e.g. Module.zero_grad) detached them."""
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+
+class FusedAdam:
+    """optim.Adam(params, lr, betas=(beta1, 0.999)) semantics of train.py:224-225 in one kernel launch."""
+
+    def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.5, 0.999), eps=1e-8):
+        self.flat = flat
+        self.hyper_host = [float(lr), float(betas[0]), float(betas[1]), float(eps), 1.0]
+        self.hyper = torch.tensor(self.hyper_host, dtype=torch.float32, device=flat.flat.device)
+        self.param_groups = [{"lr": float(lr)}]  # same handle the reference's update_lr() writes to (train.py:253-265)
+
+    def set_lr(self, lr):
+        self.param_groups[0]["lr"] = float(lr)
+        self._push()
+
+    def set_grad_scale(self, s):
+        self.hyper_host[4] = float(s)
+        self._push()
+
+    def _push(self):
+        self.hyper_host[0] = float(self.param_groups[0]["lr"])
+        self.hyper.copy_(torch.tensor(self.hyper_host, dtype=torch.float32), non_blocking=True)
+
+    def step(self):
+        f = self.flat
+        if self.hyper_host[0] != self.param_groups[0]["lr"]:
+            self._push()
+        _C.call("ngan_adam_step", f.flat, f.grad, f.exp_avg, f.exp_avg_sq, f.seg_off, f.seg_len, f.seg_active, f.seg_step,
+                len(f.params), f.chunk_seg, f.chunk_off, int(f.chunk_seg.numel()), self.hyper)
+        ops.bump_weight_epoch()  # packed conv weights are stale now
+
+
+def active_parameters(net):
+    """Parameters that take part in `forward` at the net's current stage (everything else has .grad None in torch)."""
+    mods = [net.layers]
+    fading = net.alpha_value() < 1
+    if hasattr(net, "ToIm"):
+        mods.append(net.ToIm)
+        if fading:
+            mods += [net.conv_block_list[0], net.ToIm_list[0]]
+    else:
+        mods.append(net.FromIm)
+        if fading:
+            mods += [net.conv_block_list[-1], net.FromIm_list[-1]]
+    out = []
+    for m in mods:
+        out += list(m.parameters())
+    return out
+
+
+def lr_schedule(epoch, base_lr, transit_sch, n_epochs, total_decay=1 / 100):
+    """Learning rate at `epoch` (reference update_lr, train.py:238-265): reset to base at every phase boundary,
+    exponential decay by `total_decay` over the first half of each phase, then held.  Returns None where the
+    reference leaves the optimiser's current value untouched (second half of a phase)."""
+    bounds = [0] + list(transit_sch) + [n_epochs]
+    if epoch in bounds:
+        return base_lr
+    phase = sum(epoch > t for t in transit_sch)
+    phase_len = bounds[phase + 1] - bounds[phase]
+    since = epoch - bounds[phase]
+    if since <= phase_len / 2:
+        gamma = np.exp(np.log(total_decay) / (phase_len / 2))
+        return base_lr * (gamma ** since)
+    return None
+
+
+class PGGANTrainer:
+    """One object per process (= per GPU).  `train_iteration(real)` is train.py:356-385 with sim_loss off."""
+
+    def __init__(self, generator, discriminator, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001,
+                 n_critic=1, alpha_step=1e-4, process_group=None, device_latents=False):
+        self.G, self.D = generator, discriminator
+        self.device = next(generator.parameters()).device
+        self.n_critic = n_critic
+        self.alpha_step = alpha_step
+        self.device_latents = device_latents
+        self.flat_g, self.flat_d = FlatParams(generator), FlatParams(discriminator)
+        self.opt_g = FusedAdam(self.flat_g, learning_rate, (beta1, 0.999))
+        self.opt_d = FusedAdam(self.flat_d, learning_rate, (beta1, 0.999))
+        self.d_loss = D_W_loss(generator, discriminator, drift_epsilon=drift_epsilon, check_nan=False)
+        self.gp_loss = D_grad_pen_loss(generator, discriminator, Lambda=grad_pen_lambda)
+        self.g_loss = G_W_loss(generator, discriminator, check_nan=False)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world > 1:
+            self.opt_g.set_grad_scale(1.0 / self.world)
+            self.opt_d.set_grad_scale(1.0 / self.world)
+        self.refresh_stage()
+        self._graph = None
+        ops.bump_weight_epoch()
+
+    # ---- stage bookkeeping -------------------------------------------------------------------------------
+    def refresh_stage(self):
+        """Call after any growth event (increase_resolution / a transition completing)."""
+        self.flat_g.set_active(active_parameters(self.G))
+        self.flat_d.set_active(active_parameters(self.D))
+        self._graph = None
+
+    def start_epoch(self, epoch, transit_sch=()):
+        """Per-epoch alpha advance and growth (train.py:318-333).  Returns True if the structure changed."""
+        changed = False
+        ga, da = self.G.alpha_value(), self.D.alpha_value()
+        if ga < 1 and da < 1:
+            self.G.advance_transition(self.alpha_step)
+            self.D.advance_transition(self.alpha_step)
+            changed = self.G.alpha_value() >= 1
+        elif ga < 1:
+            raise Exception('The networks are not synchronized. Gen_alpha={:.3f}, Disc_alpha={:.3f}'.format(ga, da))
+        if epoch in transit_sch:
+            self.G.increase_resolution()
+            self.D.increase_resolution()
+            changed = True
+        if changed:
+            self.refresh_stage()
+        return changed
+
+    # ---- the two half-steps ---------------------------------------------------------------------------------
+    def _latent(self, batch, z):
+        if z is not None:
+            return z
+        if self.device_latents:
+            return sample_latent_vec_device((batch, self.G.latent_dim), self.device)
+        return sample_latent_vec((batch, self.G.latent_dim), device=self.device)
+
+    def _exchange(self, flat):
+        if self.world > 1:
+            dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=self.group)  # RCCL over xGMI; 1/N is folded into Adam
+
+    def d_step(self, real, z_d=None, z_gp=None, eps=None):
+        b = real.size(0)
+        self.flat_d.ensure_grad_views()
+        self.flat_d.zero_grad()  # Discriminator_net.zero_grad(), train.py:357
+        loss, s_real, s_fake = self.d_loss(real, z=self._latent(b, z_d))  # train.py:358
+        gp = self.gp_loss(real, z=self._latent(b, z_gp), epsilon=eps)  # train.py:361
+        loss = loss + gp  # train.py:362
+        loss.backward()  # train.py:365
+        self._exchange(self.flat_d)
+        self.opt_d.step()  # train.py:366
+        return {"D_loss": loss.detach(), "score_real": s_real.detach(), "score_fake": s_fake.detach(), "D_grad_pen": gp.detach()}
+
+    def g_step(self, real, z=None):
+        b = real.size(0)
+        self.flat_g.ensure_grad_views()
+        self.flat_g.zero_grad()  # Generator_net.zero_grad(), train.py:375
+        d_params = self.flat_d.params
+        for p in d_params:  # the reference also back-propagates into the critic's weights here and discards the result
+            p.requires_grad_(False)
+        try:
+            loss, _ = self.g_loss(real, z=self._latent(b, z))  # train.py:376
+            loss.backward()  # train.py:384
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        self._exchange(self.flat_g)
+        self.opt_g.step()  # train.py:385
+        return {"G_loss": loss.detach()}
+
+    def train_iteration(self, real, z_d=None, z_gp=None, eps=None, z_g=None):
+        stats = {}
+        for _ in range(self.n_critic):  # train.py:356
+            stats.update(self.d_step(real, z_d, z_gp, eps))
+        stats.update(self.g_step(real, z_g))
+        return stats
+
+    # ---- HIP-graph capture of a whole iteration ---------------------------------------------------------------
+    def capture(self, real_example, warmup=3):
+        """Capture `train_iteration` for this batch shape into a HIP graph (latents and epsilon drawn on the GPU inside
+        the graph).  Afterwards `replay(real)` copies `real` into the static input and launches the graph."""
+        if not self.device_latents:
+            raise RuntimeError("graph capture needs device_latents=True (CPU-drawn latents cannot be replayed)")
+        self._static_real = real_example.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.train_iteration(self._static_real)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ops.bump_weight_epoch()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_stats = self.train_iteration(self._static_real)
+        self._graph = graph
+        ops.bump_weight_epoch()  # drop packed-weight buffers that live in the graph's private pool
+        return graph
+
+    def replay(self, real=None):
+        if self._graph is None:
+            raise RuntimeError("call capture() first (and again after every growth event)")
+        if real is not None:
+            self._static_real.copy_(real, non_blocking=True)
+        self._graph.replay()
+        return self._static_stats

@@ -8,7 +8,7 @@ What is imported from the reference: `models.Generator_PG`, `models.Discriminato
 `loss_functions.py` is NOT imported: its `utils` import needs parse/torchvision/cv2, which are
 not installed.  The three loss forwards (loss_functions.py:14-47, 59-74, 157-180) and the inner
 loop (train.py:357-385) are therefore replayed by `ref_step` below over the imported reference
-modules; `check_survey_pins` verifies that this replay reproduces the first-step values that
+modules; an assert in `full_fixture` verifies that this replay reproduces the first-step values that
 SURVEY.md 8(c) recorded from the reference's real loss modules (same seeds, same RNG order).
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--full]
@@ -60,6 +60,17 @@ def ref_losses(G, D, x, z_d, z_gp, eps, lam=10.0, drift=0.001):
 
 def ref_step(G, D, oG, oD, x, z_d, z_gp, eps, z_g, lam=10.0, drift=0.001, capture=None):
     """train.py:357-385 with n_critic=1 over the reference modules."""
+    if capture is not None:
+        # generator gradients BEFORE the critic update: a pin that does not go through Adam's sign-like first step
+        G.zero_grad()
+        D.zero_grad()
+        pre = -D(G(z_g)).mean()
+        pre.backward()
+        for k, p in G.named_parameters():
+            if p.grad is not None:
+                capture["Ggrad_pre/" + k] = p.grad.detach().clone().numpy()
+        capture["G_loss_pre"] = np.array(float(pre.detach()))
+        G.zero_grad()
     D.zero_grad()
     L = ref_losses(G, D, x, z_d, z_gp, eps, lam, drift)
     total = L["d_loss"] + L["gp"]
@@ -192,9 +203,10 @@ def full_fixture(models, config, name):
     out["D_of_fake"] = L["fake_score"].detach().numpy()
     out["grad_norms"] = L["norms"].detach().numpy()
     for k, v in cap.items():
-        if k.startswith(("Dgrad/", "Ggrad/")):
+        if k.startswith(("Dgrad/", "Ggrad/", "Ggrad_pre/")):
             out["cs/" + k] = np.array([float(v.astype(np.float64).sum()), float(np.abs(v.astype(np.float64)).sum())])
     out["scalars"] = np.array([scal[k] for k in ("D_loss", "score_real", "score_fake", "GP", "G_loss")], dtype=np.float64)
+    out["G_loss_pre"] = cap["G_loss_pre"]
     for k, v in checksums(G).items():
         out["Gafter_cs/" + k] = v
     for k, v in checksums(D).items():

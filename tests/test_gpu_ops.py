@@ -1,0 +1,231 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp64 CPU references of the same
+ops: forward, first-order gradients and the gradient-penalty-style second order (d/dW of |dL/dx|^2).
+Tolerances: fp32 kernels vs fp64 reference, max-norm relative error <= 2e-4 (forward / first order) and
+<= 1e-3 (second order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+SLOPE = 0.2
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def resample_ref(x, code):
+    if code == 1:
+        return F.avg_pool2d(x, 2)
+    if code == 2:
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=None)
+    return x
+
+
+def pn_ref(x):
+    return x / torch.sqrt(torch.mean(x * x, dim=1, keepdim=True) + 1e-8)
+
+
+def run_both(f_hip, f_ref, tensors, grad_names, x_name=None, tol1=2e-4, tol2=1e-3):
+    """tensors: dict name -> fp32 CPU tensor in NCHW / parameter layout.  f_* take the dict, return one tensor (NCHW-like).
+    Checks forward, grads wrt grad_names, and (if x_name) grads of sum((dL/dx)^2) wrt grad_names."""
+    ref_in = {k: v.double().clone().requires_grad_(k in grad_names or k == x_name) for k, v in tensors.items()}
+    hip_in = {k: v.to(DEV).clone().requires_grad_(k in grad_names or k == x_name) for k, v in tensors.items()}
+    out_r = f_ref(ref_in)
+    out_h = f_hip(hip_in)
+    assert out_h.shape == out_r.shape, (out_h.shape, out_r.shape)
+    assert rel(out_h, out_r) < tol1, f"forward rel err {rel(out_h, out_r)}"
+    torch.manual_seed(5)
+    v = torch.randn(out_r.shape, dtype=torch.float64)
+    names = list(grad_names) + ([x_name] if x_name and x_name not in grad_names else [])
+    gr = torch.autograd.grad((out_r * v).sum(), [ref_in[k] for k in names], create_graph=x_name is not None)
+    gh = torch.autograd.grad((out_h * v.float().to(DEV)).sum(), [hip_in[k] for k in names], create_graph=x_name is not None)
+    for k, a, b in zip(names, gh, gr):
+        assert rel(a, b) < tol1, f"grad {k} rel err {rel(a, b)}"
+    if x_name:
+        ix = names.index(x_name)
+        l2r = (gr[ix] ** 2).sum()
+        l2h = (gh[ix] ** 2).sum()
+        g2r = torch.autograd.grad(l2r, [ref_in[k] for k in names], allow_unused=True)
+        g2h = torch.autograd.grad(l2h, [hip_in[k] for k in names], allow_unused=True)
+        for k, a, b in zip(names, g2h, g2r):
+            if b is None or float(b.abs().max()) == 0.0:
+                continue
+            assert a is not None, f"second-order grad {k} missing on the HIP path"
+            assert rel(a, b) < tol2, f"second-order grad {k} rel err {rel(a, b)}"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, resample, bias
+    (2, 8, 32, 16, 16, 0, False),
+    (1, 16, 16, 16, 32, 0, True),
+    (2, 12, 20, 32, 16, 0, False),     # ragged tile edges
+    (1, 8, 8, 64, 64, 0, False),
+    (1, 4, 4, 128, 128, 0, True),
+    (2, 8, 8, 16, 16, 1, False),       # avg-pool on load (input 16x16)
+    (1, 16, 16, 32, 32, 1, False),
+    (2, 8, 8, 32, 16, 2, False),       # bilinear x2 on load (input 4x4)
+    (1, 32, 32, 16, 16, 2, False),
+    (1, 40, 72, 16, 16, 0, False),     # several tiles in both directions
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_lrelu_pn_all_orders(ngan, case):
+    B, H, W, Cin, Cout, res, use_bias = case
+    ops = ngan.ops
+    torch.manual_seed(hash(case) % 1000)
+    hin, win = (2 * H, 2 * W) if res == 1 else ((H // 2, W // 2) if res == 2 else (H, W))
+    scale = 1.3868 / np.sqrt(9 * Cin)
+    t = {"x": torch.randn(B, Cin, hin, win), "w": torch.randn(Cout, Cin, 3, 3)}
+    if use_bias:
+        t["b"] = torch.randn(Cout) * 0.5
+
+    def f_ref(d):
+        c = F.conv2d(scale * resample_ref(d["x"], res), d["w"], d.get("b"), padding=1)
+        return pn_ref(F.leaky_relu(c, SLOPE))
+
+    def f_hip(d):
+        y, _ = ops.ConvLReLUPN.apply(nhwc(d["x"]), d["w"], d.get("b"), res, scale, SLOPE)
+        return nchw(y)
+
+    run_both(f_hip, f_ref, t, [k for k in t if k != "x"], x_name="x")
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 16, 32, 0, True), (1, 8, 16, 32, 16, 1, False), (1, 8, 8, 16, 16, 2, False)])
+def test_conv_raw_all_orders(ngan, case):
+    B, H, W, Cin, Cout, res, use_bias = case
+    ops = ngan.ops
+    torch.manual_seed(11)
+    hin, win = (2 * H, 2 * W) if res == 1 else ((H // 2, W // 2) if res == 2 else (H, W))
+    scale = 0.37
+    t = {"x": torch.randn(B, Cin, hin, win), "w": torch.randn(Cout, Cin, 3, 3)}
+    if use_bias:
+        t["b"] = torch.randn(Cout)
+
+    def f_ref(d):
+        return torch.tanh(F.conv2d(scale * resample_ref(d["x"], res), d["w"], d.get("b"), padding=1))
+
+    def f_hip(d):
+        return torch.tanh(nchw(ops.Conv.apply(nhwc(d["x"]), d["w"], d.get("b"), res, scale)))
+
+    run_both(f_hip, f_ref, t, [k for k in t if k != "x"], x_name="x")
+
+
+@pytest.mark.parametrize("C", [16, 32, 64, 128])
+def test_lrelu_pixelnorm_all_orders(ngan, C):
+    ops = ngan.ops
+    torch.manual_seed(C)
+    t = {"x": torch.randn(3, C, 5, 7), "b": torch.randn(C) * 0.3}
+
+    def f_ref(d):
+        return pn_ref(F.leaky_relu(d["x"] + d["b"].view(1, -1, 1, 1), SLOPE))
+
+    def f_hip(d):
+        y, _ = ops.LReLUPN.apply(nhwc(d["x"]), d["b"], SLOPE)
+        return nchw(y)
+
+    run_both(f_hip, f_ref, t, ["b"], x_name="x")
+
+
+@pytest.mark.parametrize("pool", [False, True])
+def test_from_image_all_orders(ngan, pool):
+    ops = ngan.ops
+    torch.manual_seed(2)
+    t = {"x": torch.randn(3, 1, 12, 20), "w": torch.randn(16, 1, 1, 1), "b": torch.randn(16)}
+
+    def f_ref(d):
+        x = F.avg_pool2d(d["x"], 2) if pool else d["x"]
+        return torch.tanh(F.conv2d(x, d["w"], d["b"]))
+
+    def f_hip(d):
+        return torch.tanh(nchw(ops.FromImage.apply(nhwc(d["x"]), d["w"], d["b"], pool)))
+
+    run_both(f_hip, f_ref, t, ["w", "b"], x_name="x")
+
+
+def test_to_image_first_order(ngan):
+    ops = ngan.ops
+    torch.manual_seed(3)
+    t = {"x": torch.randn(2, 16, 9, 11), "w": torch.randn(1, 16, 1, 1) * 0.3}
+    run_both(lambda d: nchw(ops.ToImage.apply(nhwc(d["x"]), d["w"])), lambda d: torch.tanh(F.conv2d(d["x"], d["w"])),
+             t, ["x", "w"])
+
+
+@pytest.mark.parametrize("C", [1, 16])
+def test_resample_pairs(ngan, C):
+    ops = ngan.ops
+    torch.manual_seed(4)
+    t = {"x": torch.randn(2, C, 6, 10)}
+    run_both(lambda d: nchw(ops.Up2.apply(nhwc(d["x"]))) ** 2, lambda d: resample_ref(d["x"], 2) ** 2, t, [], x_name="x")
+    run_both(lambda d: nchw(ops.Pool2.apply(nhwc(d["x"]))) ** 2, lambda d: resample_ref(d["x"], 1) ** 2, t, [], x_name="x")
+
+
+def test_lerp_and_xhat(ngan):
+    ops = ngan.ops
+    torch.manual_seed(6)
+    a, b = torch.randn(2, 8, 8, 16), torch.randn(2, 8, 8, 16)
+    alpha = torch.tensor([0.3])
+    t = {"a": a, "b": b}
+    run_both(lambda d: ops.Lerp.apply(d["a"], d["b"], alpha.to(DEV)) ** 2, lambda d: (d["a"] + 0.3 * (d["b"] - d["a"])) ** 2,
+             t, ["b"], x_name="a")
+    real, fake, eps = torch.randn(3, 1, 8, 8), torch.randn(3, 1, 8, 8), torch.rand(3, 1, 1, 1)
+    got = ops.xhat(real.to(DEV), fake.to(DEV), eps.to(DEV)).cpu()
+    assert rel(got, eps * real + (1 - eps) * fake) < 1e-6
+
+
+def test_final_dot_all_orders(ngan):
+    ops = ngan.ops
+    torch.manual_seed(7)
+    t = {"x": torch.randn(3, 32, 4, 4), "w": torch.randn(1, 32, 4, 4), "b": torch.randn(1)}
+    scale = 0.11
+    run_both(lambda d: torch.tanh(ops.FinalDot.apply(nhwc(d["x"]), d["w"], d["b"], scale)),
+             lambda d: torch.tanh(F.conv2d(scale * d["x"], d["w"], d["b"]).flatten(1)), t, ["w", "b"], x_name="x")
+
+
+@pytest.mark.parametrize("B,K,S,C", [(3, 32, 4, 32), (20, 512, 16, 128)])
+def test_linear_stem(ngan, B, K, S, C):
+    ops = ngan.ops
+    torch.manual_seed(8)
+    t = {"z": torch.randn(B, K), "w": torch.randn(C * S * S, K) * 0.1}
+    scale = 0.0613
+
+    def f_ref(d):
+        h = F.linear(scale * d["z"], d["w"]).view(B, C, S, S)
+        return pn_ref(F.leaky_relu(h, SLOPE))
+
+    def f_hip(d):
+        y, _ = ops.LinearLReLUPN.apply(d["z"], d["w"], S, scale, SLOPE)
+        return nchw(y)
+
+    run_both(f_hip, f_ref, t, ["z", "w"])
+
+
+def test_sample_l2norm(ngan):
+    ops = ngan.ops
+    torch.manual_seed(9)
+    t = {"g": torch.randn(4, 1, 32, 32)}
+    run_both(lambda d: ops.SampleL2Norm.apply(d["g"]), lambda d: d["g"].norm(2, dim=(1, 2, 3)), t, ["g"])
+
+
+def test_unsupported_shapes_fail_loudly(ngan):
+    ops = ngan.ops
+    x = torch.randn(1, 4, 4, 12, device=DEV)
+    w = torch.randn(16, 12, 3, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="multiples of 16|must be"):
+        ops.ConvLReLUPN.apply(x, w, None, 0, 1.0, SLOPE)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.LReLUPN.apply(torch.randn(1, 2, 2, 16), None, SLOPE)
