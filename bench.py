@@ -1,0 +1,203 @@
+"""Benchmark of the PGGAN / WGAN-GP training step on MI355X (contract: see the task brief / DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full iteration of the reference's inner loop (train.py:357-385): D step (W loss + drift + gradient
+penalty, backward, Adam) then G step (loss, backward, Adam), n_critic = 1, at the 512x512 final stage (alpha = 1),
+batch 16 per GPU, fp32, synthetic reals 2*U[0,1)-1 already resident in HBM and unit-sphere latents drawn on the GPU.
+Rank 0 prints ONE JSON line: images/s over all ranks, plus
+  roofline     -- the dominant kernel (the MFMA 3x3 conv) timed with HIP events on its launch stream during the timed
+                  steps: achieved = algorithmic flops of those launches / their summed duration; peak = fp32 MFMA 157.3 TF
+  cpu_baseline -- the CPU oracle (oracle/pggan_oracle.py, a port of the reference's path) timed on this host's cores on a
+                  bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+G_WIDTHS = [128, 64, 32, 32, 16, 16]
+D_WIDTHS = [16, 16, 32, 32, 64, 128]
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+
+
+class ConvProbe:
+    """HIP-event timing of ngan_conv3x3_fwd launches, bucketed by kernel template instance."""
+
+    def __init__(self):
+        self.records = []  # (key, flops, e0, e1)
+
+    @staticmethod
+    def wants(name, args):
+        return name == "ngan_conv3x3_fwd"
+
+    def add(self, name, args, e0, e1):
+        b, h, w, k, n, resample, epilogue, out_mode = args[5:13]
+        key = f"conv3x3_kernel<MT={n // 16},RES={resample},EPI={epilogue},OUT={out_mode}>"
+        self.records.append((key, 2.0 * 9 * k * n * b * h * w, e0, e1))
+
+    def summary(self):
+        per = {}
+        for key, flops, e0, e1 in self.records:
+            d = per.setdefault(key, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += flops
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        return {k: {"launches": v[0], "flops": v[1], "seconds": v[2], "avg_us": v[2] / v[0] * 1e6,
+                    "tflops": v[1] / v[2] / 1e12} for k, v in per.items() if v[2] > 0}
+
+
+def build_nets(pkg, res, alpha, device):
+    torch.manual_seed(1)  # weights from torch.manual_seed(1)
+    G = pkg.models.Generator_PG(G_WIDTHS, image_size_init=16)
+    D = pkg.models.Discriminator_PG(D_WIDTHS, image_size_init=16)
+    if res != 16:
+        G.set_resolution(res, alpha)
+        D.set_resolution(res, alpha)
+    return G.to(device), D.to(device)
+
+
+def cpu_baseline(res, alpha, sample_batch, budget_s=20.0):
+    """Time the CPU oracle (port of the reference path) on this host; bounded sample of the same workload."""
+    from oracle import pggan_oracle as O
+    torch.manual_seed(1)
+    pkg = load_package()
+    G = pkg.models.Generator_PG(G_WIDTHS, image_size_init=16)
+    D = pkg.models.Discriminator_PG(D_WIDTHS, image_size_init=16)
+    if res != 16:
+        G.set_resolution(res, alpha)
+        D.set_resolution(res, alpha)
+    pg = O.as_leaf_params({k: v.detach().clone() for k, v in G.state_dict().items()})
+    pd = O.as_leaf_params({k: v.detach().clone() for k, v in D.state_dict().items()})
+    spec = O.NetSpec(image_size_init=16, slope=0.2, alpha=alpha)
+    og, od = O.make_adam(pg), O.make_adam(pd)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(123)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        x = torch.rand(sample_batch, 1, res, res) * 2 - 1
+        z = [O.sample_latent_vec((sample_batch, 512)) for _ in range(3)]
+        O.train_step(pg, spec, pd, spec, og, od, x, z[0], z[1], torch.rand(sample_batch, 1, 1, 1), z[2])
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 4:
+            break
+    return {"value": sample_batch * done / el, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{done} full iteration(s) of the oracle at {res}x{res}, batch {sample_batch}, fp32, {cores} torch threads, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--alpha", type=float, default=1.0)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay a captured HIP graph, 0: eager, -1: auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="do not time the dominant kernel with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    pkg = load_package()
+    pkg._C.lib()
+    G, D = build_nets(pkg, args.res, args.alpha, device)
+    trainer = pkg.train.PGGANTrainer(G, D, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001,
+                                     device_latents=True)
+    torch.manual_seed(123 + rank)
+    pool = [(torch.rand(args.batch, 1, args.res, args.res) * 2 - 1).to(device) for _ in range(4)]
+    torch.cuda.manual_seed(1000 + rank)
+
+    use_graph = args.graph == 1  # the probe needs eager launches; graph replay is opt-in
+    probe = None if (args.no_probe or use_graph) else ConvProbe()
+
+    def step(i):
+        if use_graph:
+            trainer.replay(pool[i % len(pool)])
+        else:
+            trainer.train_iteration(pool[i % len(pool)])
+
+    if use_graph:
+        trainer.capture(pool[0], warmup=max(1, args.warmup))
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    if probe is not None:
+        pkg._C.set_probe(probe)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    pkg._C.set_probe(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        from oracle import pggan_oracle as O
+        images = args.batch * world * args.steps
+        value = images / elapsed
+        fg, fd = O.forward_flops(G_WIDTHS, D_WIDTHS, 16, args.res, 512, args.alpha)
+        w_alg = 5 * fg + 14 * fd  # algorithmic flops per image per iteration
+        out = {"metric": "images/sec (G+D step incl. GP) at 512x512", "value": value, "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{args.res}x{args.res} stage, alpha={args.alpha}, batch {args.batch}/GPU, WGAN-GP lambda=10, "
+                                      f"drift 0.001, n_critic=1, Adam(1e-4, 0.5, 0.999), widths G{G_WIDTHS} D{D_WIDTHS}",
+                          "global_batch": args.batch * world, "resolution": args.res, "parallelism": f"dp{world}",
+                          "launch": "hip-graph replay" if use_graph else "eager"},
+               "step_tflops": value * w_alg / 1e12, "step_frac_of_fp32_mfma_peak": value * w_alg / 1e12 / world / PEAK_FP32_MFMA_TFLOPS}
+        if probe is not None and probe.records:
+            summ = probe.summary()
+            dom = max(summ, key=lambda k: summ[k]["seconds"])
+            d = summ[dom]
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "launches": d["launches"], "avg_launch_us": d["avg_us"]}
+            tot_f = sum(v["flops"] for v in summ.values())
+            tot_s = sum(v["seconds"] for v in summ.values())
+            out["conv_family"] = {"tflops": tot_f / tot_s / 1e12, "seconds_per_step": tot_s / args.steps,
+                                  "instances": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2),
+                                                    "launches_per_step": v["launches"] / args.steps} for k, v in summ.items()}}
+        else:
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.res, args.alpha, sample_batch=min(args.batch, 4))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

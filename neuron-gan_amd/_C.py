@@ -94,6 +94,17 @@ def _ptr(t, name):
     return t.data_ptr()
 
 
+_probe = None
+
+
+def set_probe(probe):
+    """Install (or remove, with None) a launch probe: an object with `wants(name, args) -> bool` and
+    `add(name, args, start_event, end_event)`.  bench.py uses it to time the dominant kernel with HIP events on
+    the launch stream; the product path runs with no probe."""
+    global _probe
+    _probe = probe
+
+
 def call(name, *args):
     """Invoke a status-returning entry point on PyTorch's current stream; tensors are passed by data pointer."""
     fn = getattr(lib(), name)
@@ -101,7 +112,14 @@ def call(name, *args):
     for i, a in enumerate(args):
         conv.append(_ptr(a, f"{name} arg {i}") if (a is None or isinstance(a, torch.Tensor)) else a)
     stream = torch.cuda.current_stream().cuda_stream
-    status = fn(*conv, stream)
+    if _probe is not None and _probe.wants(name, args):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        status = fn(*conv, stream)
+        e1.record()
+        _probe.add(name, args, e0, e1)
+    else:
+        status = fn(*conv, stream)
     if status != 0:
         msg = lib().ngan_last_error().decode()
         raise RuntimeError(f"{name} failed with status {status}: {msg}")
