@@ -14,7 +14,6 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32, HALO_H = TH + 2, HALO_W = TW + 2;
 
 struct ConvArgs {
     const float* x; const float* wp; const float* bias; float* y; float* rn;
@@ -72,32 +71,43 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// forward / dgrad kernel.  256 threads = 4 waves; tile = 8 x 32 output pixels x all N = 16*MT channels.
-// wave w owns tile rows 2w, 2w+1 -> 4 pixel groups of 16 consecutive pixels.
+// forward / dgrad kernel.  256 threads = 4 waves arranged WP (along pixels) x WN (along output channels).
+// A wave owns PGW pixel groups (16 consecutive pixels of one tile row each) x MTW 16-channel tiles; the block
+// tile is NPG = WP*PGW pixel groups laid out PCG per row, and all N = 16*MTW*WN output channels.
+// Large-spatial layers use WN = 1 and an 8x32 pixel tile; small-spatial / many-channel layers (128 ch at 16x16)
+// split the channels over the waves and shrink the pixel tile so that the launch still has >= 256 workgroups;
+// PixelNorm's channel reduction then crosses waves through LDS.
 // ---------------------------------------------------------------------------------------------------------
-template <int MT, int RES, int EPI, int OUTMODE>
+template <int MTW, int WN, int PGW, int PCG, int RES, int EPI, int OUTMODE>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[HALO_H * HALO_W * 16];
+    constexpr int WP = 4 / WN, NPG = WP * PGW, TWc = PCG * 16, THc = NPG / PCG;
+    constexpr int HW_ = TWc + 2, HH_ = THc + 2, MT = MTW * WN;
+    constexpr int TILE_ELEMS = HH_ * HW_ * 16;
+    constexpr int SS_ELEMS = (WN > 1 && EPI == 1) ? WN * NPG * 16 : 0;
+    __shared__ __attribute__((aligned(16))) float smem[TILE_ELEMS + SS_ELEMS + 4];
+    float* tile = smem;
+    float* ss_l = smem + TILE_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wp = wave / WN;
     const int p = lane & 15, q = lane >> 4;
     int t = blockIdx.x;
     const int txi = t % a.tiles_x; t /= a.tiles_x;
     const int tyi = t % a.tiles_y;
     const int b = t / a.tiles_y;
-    const int y0 = tyi * TH, x0 = txi * TW;
+    const int y0 = tyi * THc, x0 = txi * TWc;
     const int G = a.K >> 4;
 
-    f32x4 acc[4][MT];
+    f32x4 acc[PGW][MTW];
 #pragma unroll
-    for (int pg = 0; pg < 4; ++pg)
+    for (int pg = 0; pg < PGW; ++pg)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int g = 0; g < G; ++g) {
         __syncthreads();
-        for (int e = tid; e < HALO_H * HALO_W * 4; e += 256) {
+        for (int e = tid; e < HH_ * HW_ * 4; e += 256) {
             const int pix = e >> 2, c4 = e & 3;
-            const int ty = pix / HALO_W, tx = pix - ty * HALO_W;
+            const int ty = pix / HW_, tx = pix - ty * HW_;
             float4 v = load_resampled<RES>(a.x, b, y0 + ty - 1, x0 + tx - 1, g * 16 + c4 * 4, a.H, a.W, a.K);
             st4(&tile[pix * 16 + c4 * 4], v);
         }
@@ -105,40 +115,39 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
-            float xv[4][4];
+            float xv[PGW][4];
 #pragma unroll
-            for (int pg = 0; pg < 4; ++pg) {
-                const int row = wave * 2 + (pg >> 1), col = (pg & 1) * 16 + p;
-                float4 v = ld4(&tile[((row + dy) * HALO_W + col + dx) * 16 + q * 4]);
+            for (int pg = 0; pg < PGW; ++pg) {
+                const int pgi = wp * PGW + pg;
+                const int row = pgi / PCG, col = (pgi % PCG) * 16 + p;
+                float4 v = ld4(&tile[((row + dy) * HW_ + col + dx) * 16 + q * 4]);
                 xv[pg][0] = v.x; xv[pg][1] = v.y; xv[pg][2] = v.z; xv[pg][3] = v.w;
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float4 wv4 = ld4(a.wp + ((((long)tap * G + g) * MT + mt) * 64 + lane) * 4);
+            for (int mt = 0; mt < MTW; ++mt) {
+                float4 wv4 = ld4(a.wp + ((((long)tap * G + g) * MT + wn * MTW + mt) * 64 + lane) * 4);
                 const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int pg = 0; pg < 4; ++pg)
+                    for (int pg = 0; pg < PGW; ++pg)
                         acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i], xv[pg][i], acc[pg][mt], 0, 0, 0);
             }
         }
     }
 
-    // ---- epilogue: lane holds channels mt*16 + 4q + {0..3} of pixel (row, col) ----
-    float4 bv[MT];
+    // ---- epilogue: lane holds channels (wn*MTW + mt)*16 + 4q + {0..3} of pixel (row, col) ----
+    float4 bv[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) bv[mt] = a.bias ? ld4(a.bias + mt * 16 + q * 4) : f4zero();
+    for (int mt = 0; mt < MTW; ++mt) bv[mt] = a.bias ? ld4(a.bias + (wn * MTW + mt) * 16 + q * 4) : f4zero();
     const float inv_n = 1.0f / (float)a.N;
+    float4 v[PGW][MTW];
+    float ssum[PGW];
 #pragma unroll
-    for (int pg = 0; pg < 4; ++pg) {
-        const int row = wave * 2 + (pg >> 1), col = (pg & 1) * 16 + p;
-        const int gy = y0 + row, gx = x0 + col;
-        const bool valid = gy < a.H && gx < a.W;
-        float4 v[MT];
+    for (int pg = 0; pg < PGW; ++pg) {
         float ss = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MTW; ++mt) {
             float4 c = make_float4(acc[pg][mt][0] + bv[mt].x, acc[pg][mt][1] + bv[mt].y,
                                    acc[pg][mt][2] + bv[mt].z, acc[pg][mt][3] + bv[mt].w);
             if (EPI == 1) {
@@ -146,28 +155,53 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                 c.z = c.z > 0.f ? c.z : a.slope * c.z; c.w = c.w > 0.f ? c.w : a.slope * c.w;
                 ss += f4dot(c, c);
             }
-            v[mt] = c;
+            v[pg][mt] = c;
         }
         if (EPI == 1) {
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
-            const float r = sqrtf(ss * inv_n + a.eps);
+        }
+        ssum[pg] = ss;
+    }
+    if (EPI == 1 && WN > 1) {
+        if (q == 0) {
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) ss_l[(wn * NPG + wp * PGW + pg) * 16 + p] = ssum[pg];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg) {
+            float ss = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WN; ++w2) ss += ss_l[(w2 * NPG + wp * PGW + pg) * 16 + p];
+            ssum[pg] = ss;
+        }
+    }
+#pragma unroll
+    for (int pg = 0; pg < PGW; ++pg) {
+        const int pgi = wp * PGW + pg;
+        const int row = pgi / PCG, col = (pgi % PCG) * 16 + p;
+        const int gy = y0 + row, gx = x0 + col;
+        const bool valid = gy < a.H && gx < a.W;
+        if (EPI == 1) {
+            const float r = sqrtf(ssum[pg] * inv_n + a.eps);
             const float inv = 1.0f / r;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) v[mt] = f4scale(v[mt], inv);
-            if (valid && q == 0) a.rn[((long)b * a.H + gy) * a.W + gx] = r;
+            for (int mt = 0; mt < MTW; ++mt) v[pg][mt] = f4scale(v[pg][mt], inv);
+            if (valid && q == 0 && wn == 0) a.rn[((long)b * a.H + gy) * a.W + gx] = r;
         }
         if (valid) {
+            const int ch0 = wn * MTW * 16 + q * 4;
             if (OUTMODE == 0) {
-                float* o = a.y + (((long)b * a.H + gy) * a.W + gx) * a.N + q * 4;
+                float* o = a.y + (((long)b * a.H + gy) * a.W + gx) * a.N + ch0;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) st4(o + mt * 16, v[mt]);
+                for (int mt = 0; mt < MTW; ++mt) st4(o + mt * 16, v[pg][mt]);
             } else {
                 const long W2 = 2L * a.W;
-                float* o = a.y + (((long)b * 2 * a.H + 2 * gy) * W2 + 2 * gx) * a.N + q * 4;
+                float* o = a.y + (((long)b * 2 * a.H + 2 * gy) * W2 + 2 * gx) * a.N + ch0;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    float4 s = f4scale(v[mt], 0.25f);
+                for (int mt = 0; mt < MTW; ++mt) {
+                    float4 s = f4scale(v[pg][mt], 0.25f);
                     st4(o + mt * 16, s); st4(o + a.N + mt * 16, s);
                     st4(o + W2 * a.N + mt * 16, s); st4(o + W2 * a.N + a.N + mt * 16, s);
                 }
@@ -176,23 +210,65 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     }
 }
 
-template <int MT, int RES, int EPI, int OUTMODE>
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+// tile shapes: {MTW, WN, PGW, PCG}.  Per output-channel count, ordered from the largest pixel tile to the smallest.
+struct TileCfg { int mtw, wn, pgw, pcg; };
+constexpr TileCfg kCfg[4][3] = {
+    {{1, 1, 4, 2}, {1, 1, 1, 1}, {1, 1, 1, 1}},   // N = 16 : 8x32 | 4x16
+    {{2, 1, 4, 2}, {2, 1, 1, 1}, {1, 2, 1, 1}},   // N = 32 : 8x32 | 4x16 | 2x16
+    {{4, 1, 4, 2}, {2, 2, 2, 1}, {1, 4, 1, 1}},   // N = 64 : 8x32 | 4x16 | 1x16
+    {{8, 1, 4, 2}, {2, 4, 4, 1}, {2, 4, 1, 1}},   // N = 128: 8x32 | 4x16 | 1x16
+};
+constexpr int kMinBlocks = 256;  // one workgroup per CU at least
+
+inline void cfg_tile(const TileCfg& c, int& th, int& tw) {
+    const int npg = (4 / c.wn) * c.pgw;
+    tw = c.pcg * 16;
+    th = npg / c.pcg;
+}
+
+// pick the largest tile that still gives kMinBlocks workgroups and wastes < 30 % of its pixels
+int pick_cfg(int mti, int B, int H, int W) {
+    for (int i = 0; i < 3; ++i) {
+        int th, tw;
+        cfg_tile(kCfg[mti][i], th, tw);
+        const long nwg = (long)B * ngan::ceil_div(H, th) * ngan::ceil_div(W, tw);
+        const double waste = (double)nwg * th * tw / ((double)B * H * W);
+        if (nwg >= kMinBlocks && waste <= 1.3) return i;
+    }
+    return 2;
+}
+
+template <int MTI, int CI, int RES, int EPI, int OUTMODE>
+int launch_conv(ConvArgs a, hipStream_t s) {
+    constexpr TileCfg c = kCfg[MTI][CI];
+    int th, tw;
+    cfg_tile(c, th, tw);
+    a.tiles_x = ngan::ceil_div(a.W, tw);
+    a.tiles_y = ngan::ceil_div(a.H, th);
     const int grid = a.B * a.tiles_x * a.tiles_y;
-    hipLaunchKernelGGL((conv3x3_kernel<MT, RES, EPI, OUTMODE>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_kernel<c.mtw, c.wn, c.pgw, c.pcg, RES, EPI, OUTMODE>), dim3(grid), dim3(256), 0, s, a);
     return ngan::launch_status("ngan_conv3x3_fwd");
 }
 
-template <int MT>
-int dispatch_conv(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
-    if (outmode == 1) return launch_conv<MT, 0, 0, 1>(a, s);
+template <int MTI, int CI>
+int dispatch_conv2(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
+    if (outmode == 1) return launch_conv<MTI, CI, 0, 0, 1>(a, s);
     switch (res * 2 + epi) {
-        case 0: return launch_conv<MT, 0, 0, 0>(a, s);
-        case 1: return launch_conv<MT, 0, 1, 0>(a, s);
-        case 2: return launch_conv<MT, 1, 0, 0>(a, s);
-        case 3: return launch_conv<MT, 1, 1, 0>(a, s);
-        case 4: return launch_conv<MT, 2, 0, 0>(a, s);
-        default: return launch_conv<MT, 2, 1, 0>(a, s);
+        case 0: return launch_conv<MTI, CI, 0, 0, 0>(a, s);
+        case 1: return launch_conv<MTI, CI, 0, 1, 0>(a, s);
+        case 2: return launch_conv<MTI, CI, 1, 0, 0>(a, s);
+        case 3: return launch_conv<MTI, CI, 1, 1, 0>(a, s);
+        case 4: return launch_conv<MTI, CI, 2, 0, 0>(a, s);
+        default: return launch_conv<MTI, CI, 2, 1, 0>(a, s);
+    }
+}
+
+template <int MTI>
+int dispatch_conv(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
+    switch (pick_cfg(MTI, a.B, a.H, a.W)) {
+        case 0: return dispatch_conv2<MTI, 0>(a, res, epi, outmode, s);
+        case 1: return dispatch_conv2<MTI, 1>(a, res, epi, outmode, s);
+        default: return dispatch_conv2<MTI, 2>(a, res, epi, outmode, s);
     }
 }
 
@@ -210,8 +286,9 @@ struct WgradArgs {
 template <int CS>
 __device__ __forceinline__ int swz(int pix, int c) { return CS == 32 ? (c ^ ((pix & 1) << 4)) : c; }
 
-template <int COT, int CIT, int RES>
+template <int COT, int CIT, int RES, int TW>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int TH = 256 / TW, HALO_H = TH + 2, HALO_W = TW + 2, RPW = TH / 4;   // rows per wave
     constexpr int CO_S = COT * 16, CI_S = CIT * 16;
     constexpr int G_ELEMS = TH * TW * CO_S, X_ELEMS = HALO_H * HALO_W * CI_S;
     constexpr int NACC = 9 * COT * CIT;
@@ -254,9 +331,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             st4(&x_lds[pix * CI_S + swz<CI_S>(pix, c4 * 4)], v);
         }
         __syncthreads();
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = wave * 2 + rr;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
             for (int s = 0; s < TW / 4; ++s) {
                 float av[COT];
                 const int gp = r * TW + 4 * s + q;
@@ -309,7 +385,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// out[(co*K + ci)*9 + tap] = scale * sum_parts slab[part][slice][tap][co_l][ci_l]
+// out[(co*K + ci)*9 + tap] = scale * sum_parts slab[part][slice][tap][co_l][ci_l]; 16 outputs x 16 part-lanes per block
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
                                                            int nparts, int nslices, int n_ci_slices, int CO_S, int CI_S,
                                                            int K, float scale) {
@@ -317,14 +393,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int slab = 9 * CO_S * CI_S;
     const long M = (long)nslices * slab;
     const int tid = threadIdx.x;
-    const long i = (long)blockIdx.x * 64 + (tid & 63);
+    const long i = (long)blockIdx.x * 16 + (tid & 15);
     float s = 0.f;
     if (i < M)
-        for (int j = tid >> 6; j < nparts; j += 4) s += partial[(long)j * M + i];
+        for (int j = tid >> 4; j < nparts; j += 16) s += partial[(long)j * M + i];
     red[tid] = s;
     __syncthreads();
-    if (tid < 64 && i < M) {
-        s = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+    if (tid < 16 && i < M) {
+        s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += red[tid + 16 * j];
         int r = (int)(i % slab);
         const int slice = (int)(i / slab);
         const int ci_l = r % CI_S; r /= CI_S;
@@ -335,7 +413,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-struct WgradPlan { int co_s, ci_s, nslices, n_ci_slices, tiles_x, tiles_y, n_tiles, nwx; };
+struct WgradPlan { int co_s, ci_s, nslices, n_ci_slices, tiles_x, tiles_y, n_tiles, nwx, tw; };
 
 WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
     WgradPlan p;
@@ -343,10 +421,11 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
     p.ci_s = (Cin % 32 == 0) ? 32 : 16;
     p.n_ci_slices = Cin / p.ci_s;
     p.nslices = (Cout / p.co_s) * p.n_ci_slices;
-    p.tiles_x = ngan::ceil_div(W, TW);
-    p.tiles_y = ngan::ceil_div(H, TH);
+    p.tw = W <= 16 ? 16 : 32;   // 16x16-pixel tiles for narrow images, 8x32 otherwise
+    p.tiles_x = ngan::ceil_div(W, p.tw);
+    p.tiles_y = ngan::ceil_div(H, 256 / p.tw);
     p.n_tiles = B * p.tiles_x * p.tiles_y;
-    int cap = 1024 / p.nslices;
+    int cap = 512 / p.nslices;   // about two resident workgroups per CU: few slabs to reduce afterwards
     if (cap < 1) cap = 1;
     p.nwx = p.n_tiles < cap ? p.n_tiles : cap;
     return p;
@@ -355,9 +434,15 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 template <int COT, int CIT>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, hipStream_t s) {
     dim3 grid(p.nwx, p.nslices);
-    if (res == 0) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 0>), grid, dim3(256), 0, s, a);
-    else if (res == 1) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 1>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 2>), grid, dim3(256), 0, s, a);
+    if (p.tw == 32) {
+        if (res == 0) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 0, 32>), grid, dim3(256), 0, s, a);
+        else if (res == 1) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 1, 32>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 2, 32>), grid, dim3(256), 0, s, a);
+    } else {
+        if (res == 0) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 0, 16>), grid, dim3(256), 0, s, a);
+        else if (res == 1) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 1, 16>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 2, 16>), grid, dim3(256), 0, s, a);
+    }
     return ngan::launch_status("ngan_conv3x3_wgrad");
 }
 
@@ -389,13 +474,13 @@ extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float
     NGAN_REQUIRE(epilogue == 0 || rnorm, NGAN_ERR_ARG, "conv3x3_fwd: epilogue 1 needs rnorm");
     NGAN_REQUIRE(resample != NGAN_RESAMPLE_UP2 || (H % 2 == 0 && W % 2 == 0), NGAN_ERR_SHAPE,
                  "conv3x3_fwd: bilinear x2 needs even H, W");
-    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, ngan::ceil_div(W, TW), ngan::ceil_div(H, TH), slope, eps};
+    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, 0, 0, slope, eps};
     hipStream_t s = (hipStream_t)stream;
     switch (N / 16) {
-        case 1: return dispatch_conv<1>(a, resample, epilogue, out_mode, s);
-        case 2: return dispatch_conv<2>(a, resample, epilogue, out_mode, s);
-        case 4: return dispatch_conv<4>(a, resample, epilogue, out_mode, s);
-        default: return dispatch_conv<8>(a, resample, epilogue, out_mode, s);
+        case 1: return dispatch_conv<0>(a, resample, epilogue, out_mode, s);
+        case 2: return dispatch_conv<1>(a, resample, epilogue, out_mode, s);
+        case 4: return dispatch_conv<2>(a, resample, epilogue, out_mode, s);
+        default: return dispatch_conv<3>(a, resample, epilogue, out_mode, s);
     }
 }
 
@@ -424,7 +509,7 @@ extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, flo
     else st = launch_wgrad<1, 1>(a, p, resample, s);
     if (st) return st;
     const long M = (long)p.nslices * 9 * p.co_s * p.ci_s;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ngan::ceil_div(M, 64)), dim3(256), 0, s, workspace, gw, p.nwx,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ngan::ceil_div(M, 16)), dim3(256), 0, s, workspace, gw, p.nwx,
                        p.nslices, p.n_ci_slices, p.co_s, p.ci_s, Cin, scale);
     return ngan::launch_status("ngan_conv3x3_wgrad(reduce)");
 }

@@ -7,21 +7,27 @@
 namespace ngan {
 
 // out[i] = scale * sum_j partials[j*stride + i], i < M.  Fixed summation order (deterministic).
+// 16 outputs x 16 part-lanes per block so that short outputs (a bias: 16 floats) still spread over many lanes.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int M,
                                                               long stride, float* __restrict__ out, float scale) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    const long i = (long)blockIdx.x * 64 + (tid & 63);
+    const long i = (long)blockIdx.x * 16 + (tid & 15);
     float s = 0.f;
     if (i < M)
-        for (int j = tid >> 6; j < nparts; j += 4) s += partials[(long)j * stride + i];
+        for (int j = tid >> 4; j < nparts; j += 16) s += partials[(long)j * stride + i];
     red[tid] = s;
     __syncthreads();
-    if (tid < 64 && i < M) out[i] = ((red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192])) * scale;
+    if (tid < 16 && i < M) {
+        s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += red[tid + 16 * j];
+        out[i] = s * scale;
+    }
 }
 
 int reduce_partials_strided(const float* partials, int nparts, int M, long stride, float* out, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(M, 64)), dim3(256), 0, s, partials, nparts, M, stride, out, scale);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(M, 16)), dim3(256), 0, s, partials, nparts, M, stride, out, scale);
     return launch_status("reduce_partials");
 }
 
@@ -34,7 +40,7 @@ int reduce_partials(const float* partials, int nparts, int M, float* out, float 
 namespace {
 
 using ngan::ceil_div;
-constexpr int MAX_PARTS = 1024;
+constexpr int MAX_PARTS = 512;
 
 bool pow2_quads(int C) {
     if (C <= 0 || C % 4) return false;

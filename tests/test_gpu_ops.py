@@ -80,6 +80,12 @@ CONV_CASES = [
     (2, 8, 8, 32, 16, 2, False),       # bilinear x2 on load (input 4x4)
     (1, 32, 32, 16, 16, 2, False),
     (1, 40, 72, 16, 16, 0, False),     # several tiles in both directions
+    # tile-shape selection (csrc/conv3x3.hip kCfg): 4x16-pixel tiles with channels split over waves ...
+    (4, 64, 64, 16, 16, 0, False), (4, 64, 64, 16, 32, 0, False), (4, 64, 64, 16, 64, 0, True), (4, 64, 64, 16, 128, 0, False),
+    (16, 16, 16, 32, 128, 1, False),   # 1x16 tiles, 128 channels over 4 waves, pooled input
+    (16, 16, 16, 64, 64, 2, False),    # bilinear input, 64 channels
+    # ... and the 8x32 tile with many channels per wave
+    (1, 256, 256, 16, 64, 0, False), (1, 256, 256, 16, 128, 0, True),
 ]
 
 
