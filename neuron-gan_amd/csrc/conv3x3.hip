@@ -103,18 +103,54 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int g = 0; g < G; ++g) {
-        __syncthreads();
-        for (int e = tid; e < HH_ * HW_ * 4; e += 256) {
+    // Staging is split into "issue every global load" / "write LDS" so that the loads of one 16-channel group are
+    // all in flight together, and the loads for group g+1 are issued before the MFMAs of group g.
+    constexpr int NST = (HH_ * HW_ * 4 + 255) / 256;
+    constexpr bool W_ALL_TAPS = MTW <= 2;   // 9*MTW float4 of weights fit in registers: fetch a whole group at once
+    float4 stg[NST];
+    auto issue_stage = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = tid + i * 256;
             const int pix = e >> 2, c4 = e & 3;
             const int ty = pix / HW_, tx = pix - ty * HW_;
-            float4 v = load_resampled<RES>(a.x, b, y0 + ty - 1, x0 + tx - 1, g * 16 + c4 * 4, a.H, a.W, a.K);
-            st4(&tile[pix * 16 + c4 * 4], v);
+            stg[i] = (e < HH_ * HW_ * 4)
+                         ? load_resampled<RES>(a.x, b, y0 + ty - 1, x0 + tx - 1, g * 16 + c4 * 4, a.H, a.W, a.K)
+                         : f4zero();
+        }
+    };
+    auto wptr = [&](int g, int tap, int mt) {
+        return a.wp + ((((long)tap * G + g) * MT + wn * MTW + mt) * 64 + lane) * 4;
+    };
+    issue_stage(0);
+
+    for (int g = 0; g < G; ++g) {
+        float4 wall[W_ALL_TAPS ? 9 : 1][MTW];
+        float4 wpipe[2][MTW];
+        if (W_ALL_TAPS) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) wall[tap][mt] = ld4(wptr(g, tap, mt));
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) wpipe[0][mt] = ld4(wptr(g, 0, mt));
+        }
+        __syncthreads();   // every wave is done reading the previous group's tile
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = tid + i * 256;
+            if (e < HH_ * HW_ * 4) st4(&tile[e * 4], stg[i]);
         }
         __syncthreads();
+        if (g + 1 < G) issue_stage(g + 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
+            if (!W_ALL_TAPS && tap + 1 < 9) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) wpipe[(tap + 1) & 1][mt] = ld4(wptr(g, tap + 1, mt));
+            }
             float xv[PGW][4];
 #pragma unroll
             for (int pg = 0; pg < PGW; ++pg) {
@@ -125,7 +161,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
-                float4 wv4 = ld4(a.wp + ((((long)tap * G + g) * MT + wn * MTW + mt) * 64 + lane) * 4);
+                const float4 wv4 = W_ALL_TAPS ? wall[tap][mt] : wpipe[tap & 1][mt];
                 const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -316,19 +352,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int tyi = t % a.tiles_y;
         const int b = t / a.tiles_y;
         const int y0 = tyi * TH, x0 = txi * TW;
-        __syncthreads();
-        for (int e = tid; e < TH * TW * (CO_S / 4); e += 256) {
+        // issue every global load of the tile first, then write LDS (one round trip instead of one per element)
+        constexpr int NG = TH * TW * (CO_S / 4) / 256, NX = (HALO_H * HALO_W * (CI_S / 4) + 255) / 256;
+        float4 gst[NG], xst[NX];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int e = tid + i * 256;
             const int pix = e / (CO_S / 4), c4 = e % (CO_S / 4);
             const int r = pix / TW, c = pix % TW;
             const int gy = y0 + r, gx = x0 + c;
-            float4 v = (gy < a.H && gx < a.W) ? ld4(a.g + (((long)b * a.H + gy) * a.W + gx) * a.N + co0 + c4 * 4) : f4zero();
-            st4(&g_lds[pix * CO_S + swz<CO_S>(pix, c4 * 4)], v);
+            gst[i] = (gy < a.H && gx < a.W) ? ld4(a.g + (((long)b * a.H + gy) * a.W + gx) * a.N + co0 + c4 * 4) : f4zero();
         }
-        for (int e = tid; e < HALO_H * HALO_W * (CI_S / 4); e += 256) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * 256;
             const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
             const int ty = pix / HALO_W, tx = pix - ty * HALO_W;
-            float4 v = load_resampled<RES>(a.x, b, y0 + ty - 1, x0 + tx - 1, ci0 + c4 * 4, a.H, a.W, a.K);
-            st4(&x_lds[pix * CI_S + swz<CI_S>(pix, c4 * 4)], v);
+            xst[i] = (e < HALO_H * HALO_W * (CI_S / 4))
+                         ? load_resampled<RES>(a.x, b, y0 + ty - 1, x0 + tx - 1, ci0 + c4 * 4, a.H, a.W, a.K) : f4zero();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int e = tid + i * 256;
+            const int pix = e / (CO_S / 4), c4 = e % (CO_S / 4);
+            st4(&g_lds[pix * CO_S + swz<CO_S>(pix, c4 * 4)], gst[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * 256;
+            const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
+            if (e < HALO_H * HALO_W * (CI_S / 4)) st4(&x_lds[pix * CI_S + swz<CI_S>(pix, c4 * 4)], xst[i]);
         }
         __syncthreads();
         for (int rr = 0; rr < RPW; ++rr) {

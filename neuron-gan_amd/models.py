@@ -455,11 +455,23 @@ class Discriminator_PG(_ProgressiveNet):
         x = to_nhwc(x)
         if self.alpha_value() < 1:
             y_start = self.FromIm.nhwc(x, pool=True)           # FromIm(downsample(x)), pooled on load
-            y_end = self.conv_block_list[-1].nhwc(self.FromIm_list[-1].nhwc(x))
+            y_end = self._from_image_then_block(self.FromIm_list[-1], self.conv_block_list[-1], x)
             y = ops.Lerp.apply(y_start, y_end, self.alpha.reshape(1))
-        else:
-            y = self.FromIm.nhwc(x)
-        return run_layers(self.layers, y)
+            return run_layers(self.layers, y)
+        first = self.layers[0]
+        if isinstance(first, Conv2d_scale_block):
+            y = self._from_image_then_block(self.FromIm, first, x)
+            return run_layers(list(self.layers)[1:], y)
+        return run_layers(self.layers, self.FromIm.nhwc(x))
+
+    @staticmethod
+    def _from_image_then_block(from_im, block, x):
+        """block(FromImage(x)) for a down-sampling block.  FromImage is affine per pixel and AvgPool2d is linear, so
+        pool(FromImage(x)) == FromImage(pool(x)): the image is pooled while FromImage loads it and the block's first
+        conv runs without resampling -- the C-channel tensor at the image's full resolution is never written."""
+        if _resample_of(block[0]) == ops.RES_POOL2:
+            return run_layers(list(block)[1:], from_im.nhwc(x, pool=True))
+        return block.nhwc(from_im.nhwc(x))
 
     def _merge_pending_block(self):
         self.layers.insert(0, self.conv_block_list.pop(-1))
