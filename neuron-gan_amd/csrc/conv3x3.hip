@@ -246,6 +246,254 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined variant for the layers that carry most of the work: K, N in {16, 32} on large
+// images (8x32-pixel tiles).  A workgroup keeps the whole packed weight tensor in LDS, walks a band of tiles
+// (bands are assigned per XCD so that neighbouring tiles' halos hit the same L2), and issues the global loads of
+// tile t+1 before the MFMAs of tile t, so every CU always has a tile's worth of loads in flight.
+// Bilinear x2 input: the low-resolution source patch (6x18 pixels) is staged once and expanded LDS -> LDS.
+// ---------------------------------------------------------------------------------------------------------
+// LDS image of a tile: rows of LP = 40 pixels (>= 34 used), 16 floats per pixel, one plane per 16-channel group.
+// The 16-byte quad c of pixel column X is stored at quad (c ^ 2*((X >> 2) & 1)): with that rotation the 16-lane groups of
+// a ds_read_b128 (lanes = 16 consecutive pixels x 4 quads) touch 16 distinct 16-byte slots of a 256-byte bank row
+// (conflict-free; the plain layout is 2-way).  A row pitch that is a multiple of 8 pixels keeps the rotation a
+// function of the column only, so the read address is 3 registers (one per dx) + immediates.
+template <int MTW, int KG, int RES, int EPI, int OUTMODE>
+__global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
+    constexpr int THc = 8, TWc = 32, HH_ = THc + 2, HW_ = TWc + 2, NPIX = HH_ * HW_, LP = 40;
+    constexpr int PH = THc / 2 + 2, PW = TWc / 2 + 2, NPP = PH * PW;
+    constexpr int W_ELEMS = 9 * KG * MTW * 256, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int PATCH_ELEMS = RES == NGAN_RESAMPLE_UP2 ? KG * NPP * 16 : 0;
+    constexpr int N_SRC = RES == NGAN_RESAMPLE_UP2 ? KG * NPP * 4 : KG * NPIX * 4;   // float4 loads per tile
+    constexpr int NST = (N_SRC + 255) / 256;
+    constexpr int NEX = (KG * NPIX * 4 + 255) / 256;                                 // expansion items (bilinear)
+    __shared__ __attribute__((aligned(16))) float smem[W_ELEMS + TILE_ELEMS + PATCH_ELEMS];
+    float* wl = smem;
+    float* tile = smem + W_ELEMS;
+    float* patch = tile + TILE_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    constexpr int K = KG * 16, N = MTW * 16;
+
+    for (int e = tid; e < W_ELEMS / 4; e += 256) st4(wl + e * 4, ld4(a.wp + e * 4));
+
+    const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+    const int band = (n_tiles + 7) >> 3;
+    const int t_end = min((xcd + 1) * band, n_tiles);
+    int t = xcd * band + (blockIdx.x >> 3);
+    const int h = a.H >> 1, w = a.W >> 1;
+
+    // ---- tile-invariant per-thread staging descriptors (all index arithmetic happens once, here) ----
+    int s_dy[NST], s_dx[NST], s_ch[NST], s_lds[NST];   // source pixel offset from the tile origin, channel, LDS float index
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = tid + i * 256;
+        const int c4 = e & 3;
+        if (RES == NGAN_RESAMPLE_UP2) {
+            const int pp = (e >> 2) % NPP, g = (e >> 2) / NPP;
+            s_dy[i] = pp / PW - 1; s_dx[i] = pp % PW - 1; s_ch[i] = g * 16 + c4 * 4;
+            s_lds[i] = e * 4;                                   // patch is plain [g][py][px][16]
+        } else {
+            const int pix = (e >> 2) % NPIX, g = (e >> 2) / NPIX;
+            const int ty = pix / HW_, tx = pix % HW_;
+            s_dy[i] = ty - 1; s_dx[i] = tx - 1; s_ch[i] = g * 16 + c4 * 4;
+            s_lds[i] = g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+        }
+    }
+    // expansion descriptors (bilinear): destination LDS index, the 4 patch taps and whether the item exists
+    int x_dst[RES == NGAN_RESAMPLE_UP2 ? NEX : 1], x_src[RES == NGAN_RESAMPLE_UP2 ? NEX : 1];
+    int x_ty[RES == NGAN_RESAMPLE_UP2 ? NEX : 1], x_tx[RES == NGAN_RESAMPLE_UP2 ? NEX : 1];
+    if (RES == NGAN_RESAMPLE_UP2) {
+#pragma unroll
+        for (int i = 0; i < NEX; ++i) {
+            const int e = tid + i * 256;
+            const int c4 = e & 3, pix = (e >> 2) % NPIX, g = (e >> 2) / NPIX;
+            const int ty = pix / HW_, tx = pix % HW_;
+            x_ty[i] = e < KG * NPIX * 4 ? ty : -100; x_tx[i] = tx;
+            x_dst[i] = g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+            // high-res (ty-1, tx-1) relative to an even tile origin: odd offsets are "even" output rows (2i): taps (i-1, i)
+            // patch row index = low-res row - (y0/2 - 1); for offset d = ty-1: even d -> rows d/2, d/2+1 ; odd d -> (d+1)/2, (d+1)/2+1 ... see below
+            const int dy = ty - 1, dx = tx - 1;   // in [-1, 8] / [-1, 32]
+            const int ry = (dy + 1) >> 1, rx = (dx + 1) >> 1;   // first tap's patch row / col (second tap is +1)
+            x_src[i] = ((g * PH + ry) * PW + rx) * 16 + c4 * 4;
+        }
+    }
+    // MFMA B-operand read addresses: one per dx (rotation depends on the pixel column only)
+    int rd[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) rd[dx] = (p + dx) * 16 + ((q ^ ((((p + dx) >> 2) & 1) << 1)) << 2);
+
+    auto decode = [&](int tt, int& b, int& y0, int& x0) {
+        const int txi = tt % a.tiles_x; tt /= a.tiles_x;
+        const int tyi = tt % a.tiles_y;
+        b = tt / a.tiles_y;
+        y0 = tyi * THc; x0 = txi * TWc;
+    };
+    float4 stg[NST];
+    auto issue = [&](int tt) {
+        int b, y0, x0;
+        decode(tt, b, y0, x0);
+        if (RES == NGAN_RESAMPLE_UP2) {
+            const float* base = a.x + (long)b * h * w * K;
+            const int ly0 = y0 >> 1, lx0 = x0 >> 1;
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int ly = min(max(ly0 + s_dy[i], 0), h - 1), lx = min(max(lx0 + s_dx[i], 0), w - 1);
+                stg[i] = (tid + i * 256 < N_SRC) ? ld4(base + ((long)ly * w + lx) * K + s_ch[i]) : f4zero();
+            }
+        } else {
+            const float* base = a.x + (long)b * a.H * a.W * K;
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int gy = y0 + s_dy[i], gx = x0 + s_dx[i];
+                const bool ok = (tid + i * 256 < N_SRC) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                stg[i] = ok ? ld4(base + ((long)gy * a.W + gx) * K + s_ch[i]) : f4zero();
+            }
+        }
+    };
+    if (t < t_end) issue(t);
+
+    float4 bv[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) bv[mt] = a.bias ? ld4(a.bias + mt * 16 + q * 4) : f4zero();
+    const float inv_n = 1.0f / (float)N;
+
+    while (t < t_end) {
+        int b, y0, x0;
+        decode(t, b, y0, x0);
+        __syncthreads();   // previous tile's MFMAs have finished reading `tile`
+        if (RES == NGAN_RESAMPLE_UP2) {
+#pragma unroll
+            for (int i = 0; i < NST; ++i)
+                if (tid + i * 256 < N_SRC) st4(&patch[s_lds[i]], stg[i]);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NEX; ++i) {
+                if (x_ty[i] < 0) continue;
+                const int Y = y0 + x_ty[i] - 1, X = x0 + x_tx[i] - 1;
+                float4 v = f4zero();
+                if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
+                    // Y odd -> taps (i, i+1) weights (.75, .25); Y even -> taps (i-1, i) weights (.25, .75); the patch was
+                    // loaded with clamped coordinates, so border clamping needs no special case here
+                    const float wy0 = (Y & 1) ? 0.75f : 0.25f, wx0 = (X & 1) ? 0.75f : 0.25f;
+                    const float* r0 = patch + x_src[i];
+                    float4 top = f4fma(ld4(r0 + 16), 1.0f - wx0, f4scale(ld4(r0), wx0));
+                    float4 bot = f4fma(ld4(r0 + PW * 16 + 16), 1.0f - wx0, f4scale(ld4(r0 + PW * 16), wx0));
+                    v = f4fma(bot, 1.0f - wy0, f4scale(top, wy0));
+                }
+                st4(&tile[x_dst[i]], v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NST; ++i)
+                if (tid + i * 256 < N_SRC) st4(&tile[s_lds[i]], stg[i]);
+        }
+        __syncthreads();
+        const int tn = t + nper;
+        if (tn < t_end) issue(tn);   // in flight while this tile is computed
+
+        f32x4 acc[4][MTW];
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                float xv[4][4];
+#pragma unroll
+                for (int pg = 0; pg < 4; ++pg) {
+                    const int row = wave * 2 + (pg >> 1);
+                    float4 v = ld4(&tile[g * PLANE + ((row + dy) * LP + (pg & 1) * 16) * 16 + rd[dx]]);
+                    xv[pg][0] = v.x; xv[pg][1] = v.y; xv[pg][2] = v.z; xv[pg][3] = v.w;
+                }
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const float4 wv4 = ld4(&wl[((tap * KG + g) * MTW + mt) * 256 + lane * 4]);
+                    const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int pg = 0; pg < 4; ++pg)
+                            acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i], xv[pg][i], acc[pg][mt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue (same math as conv3x3_kernel with WN = 1; reciprocal square root instead of sqrt + divide) ----
+        const long img = (long)b * a.H * a.W;
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+            const int row = wave * 2 + (pg >> 1), col = (pg & 1) * 16 + p;
+            const int gy = y0 + row, gx = x0 + col;
+            const bool valid = gy < a.H && gx < a.W;
+            float4 v[MTW];
+            float ss = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                float4 c = make_float4(acc[pg][mt][0] + bv[mt].x, acc[pg][mt][1] + bv[mt].y,
+                                       acc[pg][mt][2] + bv[mt].z, acc[pg][mt][3] + bv[mt].w);
+                if (EPI == 1) {
+                    c.x = fmaxf(c.x, a.slope * c.x); c.y = fmaxf(c.y, a.slope * c.y);   // LeakyReLU, 0 <= slope <= 1
+                    c.z = fmaxf(c.z, a.slope * c.z); c.w = fmaxf(c.w, a.slope * c.w);
+                    ss += f4dot(c, c);
+                }
+                v[mt] = c;
+            }
+            if (EPI == 1) {
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                const float m = ss * inv_n + a.eps;
+                const float inv = __builtin_amdgcn_rsqf(m);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) v[mt] = f4scale(v[mt], inv);
+                if (valid && q == 0) a.rn[img + (long)gy * a.W + gx] = m * inv;
+            }
+            if (valid) {
+                if (OUTMODE == 0) {
+                    float* o = a.y + (img + (long)gy * a.W + gx) * N + q * 4;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) st4(o + mt * 16, v[mt]);
+                } else {
+                    const long W2 = 2L * a.W;
+                    float* o = a.y + (4 * img + (long)(2 * gy) * W2 + 2 * gx) * N + q * 4;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        float4 s4 = f4scale(v[mt], 0.25f);
+                        st4(o + mt * 16, s4); st4(o + N + mt * 16, s4);
+                        st4(o + W2 * N + mt * 16, s4); st4(o + W2 * N + N + mt * 16, s4);
+                    }
+                }
+            }
+        }
+        t = tn;
+    }
+}
+
+template <int MTW, int KG, int RES, int EPI, int OUTMODE>
+int launch_persist(ConvArgs a, hipStream_t s) {
+    a.tiles_x = ngan::ceil_div(a.W, 32);
+    a.tiles_y = ngan::ceil_div(a.H, 8);
+    const int n_tiles = a.B * a.tiles_x * a.tiles_y;
+    const int lds = 4 * (9 * KG * MTW * 256 + KG * 10 * 40 * 16 + (RES == 2 ? KG * 6 * 18 * 16 : 0));
+    int per_cu = (160 * 1024) / lds;
+    if (per_cu > 4) per_cu = 4;
+    int grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    grid &= ~7;
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL((conv3x3_persist_kernel<MTW, KG, RES, EPI, OUTMODE>), dim3(grid), dim3(256), 0, s, a, n_tiles);
+    return ngan::launch_status("ngan_conv3x3_fwd(persistent)");
+}
+
+template <int MTW, int KG>
+int dispatch_persist(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
+    if (outmode == 1) return launch_persist<MTW, KG, 0, 0, 1>(a, s);
+    if (res == 0) return epi ? launch_persist<MTW, KG, 0, 1, 0>(a, s) : launch_persist<MTW, KG, 0, 0, 0>(a, s);
+    return epi ? launch_persist<MTW, KG, 2, 1, 0>(a, s) : launch_persist<MTW, KG, 2, 0, 0>(a, s);
+}
+
 // tile shapes: {MTW, WN, PGW, PCG}.  Per output-channel count, ordered from the largest pixel tile to the smallest.
 struct TileCfg { int mtw, wn, pgw, pcg; };
 constexpr TileCfg kCfg[4][3] = {
@@ -530,6 +778,13 @@ extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float
                  "conv3x3_fwd: bilinear x2 needs even H, W");
     ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, 0, 0, slope, eps};
     hipStream_t s = (hipStream_t)stream;
+    if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && pick_cfg(N / 16 - 1, B, H, W) == 0) {
+        // large image, few channels: persistent pipelined kernel
+        if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, s)
+                                    : dispatch_persist<1, 2>(a, resample, epilogue, out_mode, s);
+        return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, s)
+                       : dispatch_persist<2, 2>(a, resample, epilogue, out_mode, s);
+    }
     switch (N / 16) {
         case 1: return dispatch_conv<0>(a, resample, epilogue, out_mode, s);
         case 2: return dispatch_conv<1>(a, resample, epilogue, out_mode, s);
