@@ -571,119 +571,110 @@ template <int CS>
 __device__ __forceinline__ int swz(int pix, int c) { return CS == 32 ? (c ^ ((pix & 1) << 4)) : c; }
 
 template <int COT, int CIT, int RES, int TW>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-    constexpr int TH = 256 / TW, HALO_H = TH + 2, HALO_W = TW + 2, RPW = TH / 4;   // rows per wave
+__global__ __launch_bounds__(256, (COT * CIT == 1) ? 4 : 2) void wgrad_kernel(WgradArgs a) {
+    constexpr int TH = 256 / TW, HALO_H = TH + 2, HALO_W = TW + 2;
     constexpr int CO_S = COT * 16, CI_S = CIT * 16;
+    constexpr int WO = COT * CIT, WR = 4 / WO, RPW = TH / WR;   // waves along outputs / along rows; rows per wave
     constexpr int G_ELEMS = TH * TW * CO_S, X_ELEMS = HALO_H * HALO_W * CI_S;
-    constexpr int NACC = 9 * COT * CIT;
-    constexpr int RED_ELEMS = NACC * 64 * 4;
+    constexpr int RED_ELEMS = 4 * 9 * 64 * 4;
     constexpr int SMEM = (G_ELEMS + X_ELEMS) > RED_ELEMS ? (G_ELEMS + X_ELEMS) : RED_ELEMS;
+    constexpr int NG = TH * TW * (CO_S / 4) / 256, NXI = HALO_H * HALO_W * (CI_S / 4), NX = (NXI + 255) / 256;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* g_lds = smem;
     float* x_lds = smem + G_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, q = lane >> 4;
+    const int wo = wave % WO, wr = wave / WO;
+    const int cot = wo / CIT, cit = wo % CIT;        // this wave's 16x16 (cout, cin) sub-slice, all 9 taps
     const int slice = blockIdx.y;
     const int co0 = (slice / a.n_ci_slices) * CO_S, ci0 = (slice % a.n_ci_slices) * CI_S;
 
-    f32x4 acc[9][COT][CIT];
+    // tile-invariant staging descriptors
+    int g_r[NG], g_c[NG], g_ch[NG], g_l[NG];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int i = 0; i < NG; ++i) {
+        const int e = tid + i * 256;
+        const int pix = e / (CO_S / 4), c4 = e % (CO_S / 4);
+        g_r[i] = pix / TW; g_c[i] = pix % TW; g_ch[i] = co0 + c4 * 4;
+        g_l[i] = pix * CO_S + swz<CO_S>(pix, c4 * 4);
+    }
+    int x_r[NX], x_c[NX], x_ch[NX], x_l[NX];
 #pragma unroll
-        for (int i = 0; i < COT; ++i)
-#pragma unroll
-            for (int j = 0; j < CIT; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NX; ++i) {
+        const int e = tid + i * 256;
+        const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
+        x_r[i] = e < NXI ? pix / HALO_W - 1 : -1000; x_c[i] = pix % HALO_W - 1; x_ch[i] = ci0 + c4 * 4;
+        x_l[i] = pix * CI_S + swz<CI_S>(pix, c4 * 4);
+    }
 
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 gst[NG], xst[NX];
+    auto issue = [&](int tile) {
         int t = tile;
         const int txi = t % a.tiles_x; t /= a.tiles_x;
         const int tyi = t % a.tiles_y;
         const int b = t / a.tiles_y;
         const int y0 = tyi * TH, x0 = txi * TW;
-        // issue every global load of the tile first, then write LDS (one round trip instead of one per element)
-        constexpr int NG = TH * TW * (CO_S / 4) / 256, NX = (HALO_H * HALO_W * (CI_S / 4) + 255) / 256;
-        float4 gst[NG], xst[NX];
+        const float* gb = a.g + (long)b * a.H * a.W * a.N;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
-            const int e = tid + i * 256;
-            const int pix = e / (CO_S / 4), c4 = e % (CO_S / 4);
-            const int r = pix / TW, c = pix % TW;
-            const int gy = y0 + r, gx = x0 + c;
-            gst[i] = (gy < a.H && gx < a.W) ? ld4(a.g + (((long)b * a.H + gy) * a.W + gx) * a.N + co0 + c4 * 4) : f4zero();
+            const int gy = y0 + g_r[i], gx = x0 + g_c[i];
+            gst[i] = (gy < a.H && gx < a.W) ? ld4(gb + ((long)gy * a.W + gx) * a.N + g_ch[i]) : f4zero();
         }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int e = tid + i * 256;
-            const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
-            const int ty = pix / HALO_W, tx = pix - ty * HALO_W;
-            xst[i] = (e < HALO_H * HALO_W * (CI_S / 4))
-                         ? load_resampled<RES>(a.x, b, y0 + ty - 1, x0 + tx - 1, ci0 + c4 * 4, a.H, a.W, a.K) : f4zero();
-        }
+        for (int i = 0; i < NX; ++i)
+            xst[i] = x_r[i] > -1000 ? load_resampled<RES>(a.x, b, y0 + x_r[i], x0 + x_c[i], x_ch[i], a.H, a.W, a.K) : f4zero();
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.n_tiles) issue(tile);
+    while (tile < a.n_tiles) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int e = tid + i * 256;
-            const int pix = e / (CO_S / 4), c4 = e % (CO_S / 4);
-            st4(&g_lds[pix * CO_S + swz<CO_S>(pix, c4 * 4)], gst[i]);
-        }
+        for (int i = 0; i < NG; ++i) st4(&g_lds[g_l[i]], gst[i]);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int e = tid + i * 256;
-            const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
-            if (e < HALO_H * HALO_W * (CI_S / 4)) st4(&x_lds[pix * CI_S + swz<CI_S>(pix, c4 * 4)], xst[i]);
-        }
+        for (int i = 0; i < NX; ++i)
+            if (x_r[i] > -1000) st4(&x_lds[x_l[i]], xst[i]);
         __syncthreads();
+        const int tn = tile + gridDim.x;
+        if (tn < a.n_tiles) issue(tn);   // next tile's loads are in flight during the MFMAs
         for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave * RPW + rr;
+            const int r = wr * RPW + rr;
+#pragma unroll 2
             for (int s = 0; s < TW / 4; ++s) {
-                float av[COT];
                 const int gp = r * TW + 4 * s + q;
-#pragma unroll
-                for (int i = 0; i < COT; ++i) av[i] = g_lds[gp * CO_S + swz<CO_S>(gp, i * 16 + p)];
+                const float av = g_lds[gp * CO_S + swz<CO_S>(gp, cot * 16 + p)];
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int dy = tap / 3, dx = tap % 3;
                     const int xp = (r + dy) * HALO_W + 4 * s + q + dx;
-#pragma unroll
-                    for (int j = 0; j < CIT; ++j) {
-                        const float bvv = x_lds[xp * CI_S + swz<CI_S>(xp, j * 16 + p)];
-#pragma unroll
-                        for (int i = 0; i < COT; ++i)
-                            acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bvv, acc[tap][i][j], 0, 0, 0);
-                    }
+                    const float bvv = x_lds[xp * CI_S + swz<CI_S>(xp, cit * 16 + p)];
+                    acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv, acc[tap], 0, 0, 0);
                 }
             }
         }
+        tile = tn;
     }
 
-    // ---- sum the 4 waves through LDS (fixed order), then write this block's slab ----
+    // ---- sum the WR row-waves of each sub-slice through LDS (fixed order), then write this block's slab ----
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(smem);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int i = 0; i < COT; ++i)
-#pragma unroll
-                    for (int j = 0; j < CIT; ++j) {
-                        const int idx = (t * COT + i) * CIT + j;
-                        float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
-                        if (w > 0) v = f4add(v, red[idx * 64 + lane]);
-                        red[idx * 64 + lane] = v;
-                    }
-        }
-        __syncthreads();
-    }
+    for (int t = 0; t < 9; ++t)
+        red[(wave * 9 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
     float* slab = a.partial + ((long)blockIdx.x * gridDim.y + slice) * (9 * CO_S * CI_S);
-    for (int e = tid; e < NACC * 64; e += 256) {
-        const int idx = e >> 6, l = e & 63;
-        const float4 v = red[e];
-        const int tap = idx / (COT * CIT), i = (idx / CIT) % COT, j = idx % CIT;
-        const int ci_l = j * 16 + (l & 15), co_l = i * 16 + 4 * (l >> 4);
-        float* o = slab + ((long)tap * CO_S + co_l) * CI_S + ci_l;
-        o[0] = v.x; o[CI_S] = v.y; o[2 * CI_S] = v.z; o[3 * CI_S] = v.w;
+    for (int e = tid; e < WO * 9 * 64; e += 256) {
+        const int l = e & 63, t = (e >> 6) % 9, o = (e >> 6) / 9;
+        float4 v = red[(o * 9 + t) * 64 + l];               // wave index = wr*WO + wo
+#pragma unroll
+        for (int k = 1; k < WR; ++k) v = f4add(v, red[((k * WO + o) * 9 + t) * 64 + l]);
+        const int ci_l = (o % CIT) * 16 + (l & 15), co_l = (o / CIT) * 16 + 4 * (l >> 4);
+        float* op = slab + ((long)t * CO_S + co_l) * CI_S + ci_l;
+        op[0] = v.x; op[CI_S] = v.y; op[2 * CI_S] = v.z; op[3 * CI_S] = v.w;
     }
 }
 
