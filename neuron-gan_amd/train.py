@@ -36,9 +36,7 @@ class FlatParams:
         self.params = list(net.parameters())
         self.names = [n for n, _ in net.named_parameters()]
         assert self.params, "network has no parameters"
-        dev = self.params[0].device
-        if dev.type != "cuda":
-            raise RuntimeError("FlatParams needs the network on the GPU (call net.to('cuda') first)")
+        dev = self.params[0].device  # CPU is allowed for host-logic tests; the fused Adam kernel itself needs the GPU
         offs, total = [], 0
         for p in self.params:
             offs.append(total)
@@ -113,6 +111,16 @@ class FusedAdam:
         _C.call("ngan_adam_step", f.flat, f.grad, f.exp_avg, f.exp_avg_sq, f.seg_off, f.seg_len, f.seg_active, f.seg_step,
                 len(f.params), f.chunk_seg, f.chunk_off, int(f.chunk_seg.numel()), self.hyper)
         ops.bump_weight_epoch()  # packed conv weights are stale now
+
+
+def exchange_gradients(flat: FlatParams, world: int, group=None):
+    """Data-parallel gradient exchange: ONE all-reduce(SUM) over the net's flat gradient buffer (RCCL over xGMI on the
+    GPU; gloo in the CPU tests).  The 1/world factor is not applied here -- it is folded into the fused Adam kernel
+    (`FusedAdam.set_grad_scale`), so the averaged gradient never makes an extra pass through HBM.  No op couples
+    samples (PixelNorm is per pixel, every loss is a batch mean), so N ranks x batch b with this exchange equals
+    one rank x batch N*b up to fp32 summation order."""
+    if world > 1:
+        dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)
 
 
 def active_parameters(net):
@@ -208,8 +216,7 @@ class PGGANTrainer:
         return sample_latent_vec((batch, self.G.latent_dim), device=self.device)
 
     def _exchange(self, flat):
-        if self.world > 1:
-            dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=self.group)  # RCCL over xGMI; 1/N is folded into Adam
+        exchange_gradients(flat, self.world, self.group)
 
     def d_step(self, real, z_d=None, z_gp=None, eps=None):
         b = real.size(0)

@@ -1,0 +1,86 @@
+"""World-size-2 data-parallel checks on the CPU (gloo): the flat-gradient exchange of the step driver, and the
+data-parallel equivalence the design relies on: 2 ranks x batch b with summed gradients scaled by 1/2
+== 1 rank x batch 2b.  The per-rank gradients come from the CPU oracle; the exchange is the product's code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fixture):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import load_package
+        from conftest import load_golden, split_state
+        from oracle import pggan_oracle as O
+        pkg = load_package()
+        torch.set_num_threads(2)
+        fix = load_golden(fixture)
+        res, alpha, init, latent, batch, lr = fix["meta"]
+        batch = int(batch)
+        D = pkg.models.Discriminator_PG([16, 16, 32], image_size_init=int(init))
+        D.set_resolution(int(res), float(alpha))
+        D.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "D/").items()})
+        flat = pkg.train.FlatParams(D)
+        flat.set_active(pkg.train.active_parameters(D))
+
+        # 1. the exchange is one SUM all-reduce over the whole flat buffer
+        flat.grad.fill_(float(rank + 1))
+        pkg.train.exchange_gradients(flat, world)
+        assert torch.all(flat.grad == 3.0)
+
+        # 2. data-parallel equivalence with oracle gradients
+        spec = O.NetSpec(image_size_init=int(init), slope=0.2, alpha=float(alpha))
+        pg = O.as_leaf_params(split_state(fix, "G/"))
+        t = lambda k: torch.from_numpy(fix[k])
+
+        def d_grads(sl):
+            pd = O.as_leaf_params(split_state(fix, "D/"))
+            loss, _, _ = O.d_w_loss(pg, spec, pd, spec, t("real")[sl], t("z_d")[sl], 0.001)
+            gp = O.grad_penalty(pg, spec, pd, spec, t("real")[sl], t("z_gp")[sl], t("eps")[sl], 10.0)
+            (loss + gp).backward()
+            return {k: v.grad for k, v in pd.items() if v.grad is not None}
+
+        half = batch // world
+        mine = d_grads(slice(rank * half, (rank + 1) * half))
+        flat.zero_grad()
+        for name, p in zip(flat.names, flat.params):
+            if name in mine:
+                p.grad.add_(mine[name])          # what autograd's AccumulateGrad does into the flat views
+        pkg.train.exchange_gradients(flat, world)
+        full = d_grads(slice(0, batch))
+        gmax = max(float(v.abs().max()) for v in full.values())
+        for name, p in zip(flat.names, flat.params):
+            if name in full:
+                got = p.grad / world            # the 1/world factor the fused Adam applies (grad_scale)
+                # (the last bias' gradient is a cancellation of -1 + 1: compare against the overall gradient scale too)
+                err = float((got - full[name]).abs().max() / (full[name].abs().max() + 1e-2 * gmax))
+                assert err < 1e-5, (name, err)
+        # inactive tensors stay exactly zero on every rank
+        for a, p in zip(flat.active_host, flat.params):
+            if not a:
+                assert float(p.grad.abs().max()) == 0.0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixture", ["small_res8_warm", "small_res16_fade_warm"])
+def test_two_rank_gradient_exchange_equals_big_batch(fixture):
+    mp.spawn(_worker, args=(2, _free_port(), fixture), nprocs=2, join=True)

@@ -1,0 +1,196 @@
+"""CPU-only checks of the host side: the C-ABI library and its symbols, the module tree / state_dict keys / growth
+state machine mirrored from the reference, initialisation parity from a seed, the config module, the latent sampler,
+the LR schedule, and loud failure (no fallback) when tensors are not on the GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, split_state
+
+
+@pytest.fixture(scope="session")
+def built(ngan):
+    if not os.path.exists(ngan._C.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ngan
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(ROOT, "include", "ngan.h")).read()
+    declared = set(re.findall(r"\b(ngan_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 32
+    lib = ctypes.CDLL(built._C.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in include/ngan.h but not exported"
+    assert declared == set(built._C.exported_symbols()), "ctypes signature table and header disagree"
+    assert built._C.version().startswith("ngan-hip")
+
+
+def test_invalid_arguments_return_status_not_crash(built):
+    lib = built._C.lib()
+    # null pointers / bad shapes are rejected on the host before any launch (no GPU needed)
+    assert lib.ngan_conv3x3_fwd(None, None, None, None, None, 1, 8, 8, 16, 16, 0, 0, 0, 0.2, 1e-8, None) < 0
+    assert b"null" in lib.ngan_last_error()
+    assert built._C.wgrad_workspace_bytes(1, 8, 8, 16, 16) > 0
+    assert built._C.wgrad_workspace_bytes(1, 8, 8, 12, 16) == 0
+
+
+def test_no_cpu_fallback(ngan):
+    G = ngan.models.Generator_PG([32, 16], image_size_init=4, latent_dim=32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G(torch.randn(2, 32))
+    D = ngan.models.Discriminator_PG([16, 32], image_size_init=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        D(torch.randn(2, 1, 4, 4))
+
+
+@pytest.mark.parametrize("name", ["small_fresh4", "small_res8_init", "small_res16_fade_init", "small_res16_warm"])
+def test_state_dict_keys_match_reference(ngan, name):
+    fix = load_golden(name)
+    res, alpha, init, latent, _, _ = fix["meta"]
+    G = ngan.models.Generator_PG([32, 16, 16], image_size_init=int(init), latent_dim=int(latent))
+    D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=int(init))
+    if int(res) != int(init):
+        G.set_resolution(int(res), float(alpha))
+        D.set_resolution(int(res), float(alpha))
+    ref_g, ref_d = split_state(fix, "G/"), split_state(fix, "D/")
+    assert list(G.state_dict().keys()) == list(ref_g.keys())
+    assert list(D.state_dict().keys()) == list(ref_d.keys())
+    for k, v in G.state_dict().items():
+        assert tuple(v.shape) == ref_g[k].shape, k
+    for k, v in D.state_dict().items():
+        assert tuple(v.shape) == ref_d[k].shape, k
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in ref_g.items()})
+    D.load_state_dict({k: torch.from_numpy(v) for k, v in ref_d.items()})
+    assert abs(D.alpha_value() - float(alpha)) < 1e-7
+
+
+def test_full_width_keys_and_init_from_seed(ngan):
+    """SURVEY.md 3.5 key lists and 8(a1) initialisation pins (torch.manual_seed(1), G then D)."""
+    cfg = ngan.config
+    torch.manual_seed(1)
+    G = ngan.models.Generator_PG(cfg.N_gen_features, image_size_init=16)
+    D = ngan.models.Discriminator_PG(cfg.N_dis_features, image_size_init=16)
+    sg, sd = G.state_dict(), D.state_dict()
+    assert abs(float(sg["layers.0.weight"].abs().sum()) - 820408.476) < 0.5
+    assert abs(float(sg["layers.4.weight"].abs().sum()) - 4802.032) < 0.01
+    assert abs(float(sd["layers.0.weight"].abs().sum()) - 4800.991) < 0.01
+    assert abs(float(sd["layers.3.weight"].abs().sum()) - 200.369) < 0.001
+    assert "alpha" in sd and "alpha" not in sg  # D's alpha is persistent, G's is not (models.py:292, 465)
+    assert not any("bias" in k for k in sg)
+    assert tuple(sg["ToIm.layers.0.weight"].shape) == (1, 128, 1, 1) and tuple(sd["FromIm.conv.weight"].shape) == (128, 1, 1, 1)
+    fix = load_golden("full_C1")
+    for k, v in sg.items():
+        if v.numel() > 1:
+            assert abs(float(v.double().abs().sum()) - fix["Ginit_cs/" + k][1]) < 1e-9 * fix["Ginit_cs/" + k][1], k
+    G.set_resolution(256)
+    D.set_resolution(256)
+    assert list(G.state_dict().keys()) == ["layers.0.weight", "layers.4.weight"] + [f"layers.{i}.{j}.weight" for i in (7, 8, 9, 10) for j in (1, 4)] + \
+        ["conv_block_list.0.1.weight", "conv_block_list.0.4.weight", "ToIm_list.0.layers.0.weight", "ToIm.layers.0.weight"]
+    assert list(D.state_dict().keys())[:9] == ["alpha"] + [f"layers.{i}.{j}.weight" for i in (0, 1, 2, 3) for j in (1, 4)]
+    assert G.saved_attrs == ['LeakyReLU_neg_slope', 'N_colors', 'N_features_per_layer', 'N_layers', 'N_layers_max', 'image_size',
+                             'image_size_init', 'image_size_max', 'latent_dim', 'training', 'alpha']
+
+
+def test_growth_state_machine(ngan):
+    G = ngan.models.Generator_PG([32, 16, 16], image_size_init=4, latent_dim=32)
+    D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=4)
+    assert G.image_size_max == 16 and D.image_size_max == 16 and G.N_layers == 1
+    with pytest.raises(AssertionError):
+        G.set_resolution(12)
+    with pytest.raises(AssertionError):
+        G.set_resolution(32)
+    G.increase_resolution()
+    D.increase_resolution()
+    assert G.alpha_value() == 0.0 and G.image_size == 8 and G.N_layers == 2 and len(G.conv_block_list) == 2
+    with pytest.raises(AssertionError, match="previous transition"):
+        G.increase_resolution()
+    # fp32 accumulation of 1e-4 needs exactly 10 000 calls and ends at 1.0000535
+    n = 0
+    while G.alpha_value() < 1:
+        G.advance_transition(0.0001)
+        D.advance_transition(0.0001)
+        n += 1
+    assert n == 10000 and abs(G.alpha_value() - 1.0000535) < 1e-6
+    assert float(G.alpha) == pytest.approx(G.alpha_value()) and float(D.alpha) == pytest.approx(D.alpha_value())
+    assert len(G.conv_block_list) == 1 and len(G.ToIm_list) == 1 and len(G.layers) == 8
+    assert len(D.conv_block_list) == 1 and len(D.FromIm_list) == 1 and isinstance(D.layers[0], ngan.models.Conv2d_scale_block)
+    G.increase_resolution()
+    n = 0
+    while G.alpha_value() < 1:
+        G.advance_transition(0.05)
+        n += 1
+    assert n == 20
+    with pytest.raises(AssertionError):
+        G.increase_resolution()  # already at the maximum size
+
+
+def test_config_module(ngan, tmp_path):
+    cfg = ngan.config
+    assert cfg.latent_dim == 512 and cfg.N_gen_features == [128, 64, 32, 32, 16, 16] and cfg.grad_pen_lambda == 10
+    assert cfg.beta1 == 0.5 and cfg.learning_rate == 1e-4 and cfg.drift_epsilon == 0.001 and cfg.n_critic == 1
+    with pytest.raises(ValueError, match="not defined"):
+        cfg.set_configs(no_such_option=1)
+    user = tmp_path / "my_config.py"
+    user.write_text("ID = '0042'\ntransit_period = 20\nalpha_step = 0.1\nN_epochs = 200\nbatch_size = 4\n")
+    saved = {k: getattr(cfg, k) for k in cfg.configs_name}
+    try:
+        cfg.import_configs(str(user), {"seed": 9})
+        assert cfg.transit_sch == [20, 40, 60, 80, 100] and cfg.seed == 9 and cfg.batch_size == 4
+        bad = tmp_path / "bad.py"
+        bad.write_text("bogus = 1\n")
+        with pytest.raises(ValueError, match="not defined"):
+            cfg.import_configs(str(bad))
+        tight = tmp_path / "tight.py"
+        tight.write_text("ID = '0043'\ntransit_period = 5\nalpha_step = 0.1\nN_epochs = 200\n")
+        with pytest.raises(AssertionError, match="separated"):
+            cfg.import_configs(str(tight))
+    finally:
+        for k, v in saved.items():
+            setattr(cfg, k, v)
+
+
+def test_latent_sampler(ngan):
+    torch.manual_seed(7)
+    z = ngan.utils.sample_latent_vec((4, 512))
+    assert np.allclose(z[0, :3].numpy(), [-0.03830601, 0.01847874, 0.04198530], atol=1e-7)
+    state = torch.get_rng_state()
+    a = ngan.utils.sample_latent_vec((2, 8), seed=5)
+    assert torch.equal(state, torch.get_rng_state()), "seeded draw must restore the global RNG state (utils.py:66, 84)"
+    assert torch.equal(a, ngan.utils.sample_latent_vec((2, 8), seed=5))  # memoised
+    u = ngan.utils.sample_latent_vec((3, 5), mode='rand')
+    assert float(u.min()) >= -1 and float(u.max()) < 1
+    with pytest.raises(ValueError):
+        ngan.utils.sample_latent_vec((1, 2), mode='other')
+
+
+def test_lr_schedule(ngan):
+    f = ngan.train.lr_schedule
+    sch, n = [100, 200], 300
+    assert f(0, 1e-4, sch, n) == 1e-4 and f(100, 1e-4, sch, n) == 1e-4 and f(300, 1e-4, sch, n) == 1e-4
+    gamma = np.exp(np.log(1 / 100) / 50)
+    assert f(10, 1e-4, sch, n) == pytest.approx(1e-4 * gamma ** 10)
+    assert f(50, 1e-4, sch, n) == pytest.approx(1e-6)
+    assert f(51, 1e-4, sch, n) is None          # second half of a phase: the optimiser keeps its value (train.py:260)
+    assert f(130, 1e-4, sch, n) == pytest.approx(1e-4 * gamma ** 30)
+
+
+def test_flat_params_and_active_set(ngan):
+    D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=4)
+    D.set_resolution(8, 0.5)
+    flat = ngan.train.FlatParams(D)
+    assert flat.total % 64 == 0 and all(o % 64 == 0 for o in flat.offsets)
+    for p, off in zip(flat.params, flat.offsets):
+        assert p.data_ptr() == flat.flat.data_ptr() + 4 * off and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * off
+    act = {id(p) for p in ngan.train.active_parameters(D)}
+    names = {n for n, p in D.named_parameters() if id(p) in act}
+    assert names == {"layers.0.weight", "layers.0.bias", "layers.3.weight", "layers.3.bias", "FromIm.conv.weight", "FromIm.conv.bias",
+                     "conv_block_list.1.1.weight", "conv_block_list.1.4.weight", "FromIm_list.1.conv.weight", "FromIm_list.1.conv.bias"}
+    sd_before = {k: v.clone() for k, v in D.state_dict().items()}
+    D.load_state_dict(sd_before)  # in-place copy keeps the views
+    assert flat.params[0].data_ptr() == flat.flat.data_ptr()
