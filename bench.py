@@ -34,8 +34,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 class ConvProbe:
     """HIP-event timing of ngan_conv3x3_fwd launches, bucketed by kernel template instance."""
 
-    def __init__(self):
+    def __init__(self, name_of):
         self.records = []  # (key, flops, e0, e1)
+        self.name_of = name_of
 
     @staticmethod
     def wants(name, args):
@@ -43,7 +44,7 @@ class ConvProbe:
 
     def add(self, name, args, e0, e1):
         b, h, w, k, n, resample, epilogue, out_mode = args[5:13]
-        key = f"conv3x3_kernel<MT={n // 16},RES={resample},EPI={epilogue},OUT={out_mode}>"
+        key = self.name_of(b, h, w, k, n, resample, epilogue, out_mode)   # the template instance, as rocprofv3 names it
         self.records.append((key, 2.0 * 9 * k * n * b * h * w, e0, e1))
 
     def summary(self):
@@ -67,7 +68,7 @@ def build_nets(pkg, res, alpha, device):
     return G.to(device), D.to(device)
 
 
-def cpu_baseline(res, alpha, sample_batch, budget_s=20.0):
+def cpu_baseline(res, alpha, sample_batch, budget_s=12.0):
     """Time the CPU oracle (port of the reference path) on this host; bounded sample of the same workload."""
     from oracle import pggan_oracle as O
     torch.manual_seed(1)
@@ -81,7 +82,8 @@ def cpu_baseline(res, alpha, sample_batch, budget_s=20.0):
     pd = O.as_leaf_params({k: v.detach().clone() for k, v in D.state_dict().items()})
     spec = O.NetSpec(image_size_init=16, slope=0.2, alpha=alpha)
     og, od = O.make_adam(pg), O.make_adam(pd)
-    cores = os.cpu_count() or 1
+    # the box gives one GPU's job a 16-core share of the host; os.cpu_count() reports the whole machine
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     torch.manual_seed(123)
     done, t0 = 0, time.perf_counter()
@@ -91,7 +93,7 @@ def cpu_baseline(res, alpha, sample_batch, budget_s=20.0):
         O.train_step(pg, spec, pd, spec, og, od, x, z[0], z[1], torch.rand(sample_batch, 1, 1, 1), z[2])
         done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 4:
+        if el > budget_s or done >= 8:
             break
     return {"value": sample_batch * done / el, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{done} full iteration(s) of the oracle at {res}x{res}, batch {sample_batch}, fp32, {cores} torch threads, {el:.1f} s"}
@@ -130,8 +132,9 @@ def main():
     pool = [(torch.rand(args.batch, 1, args.res, args.res) * 2 - 1).to(device) for _ in range(4)]
     torch.cuda.manual_seed(1000 + rank)
 
-    use_graph = args.graph == 1  # the probe needs eager launches; graph replay is opt-in
-    probe = None if (args.no_probe or use_graph) else ConvProbe()
+    # launch mode: HIP-graph replay of the whole iteration on one GPU (captured once), eager under torchrun
+    use_graph = args.graph == 1 or (args.graph == -1 and world == 1)
+    probe = None if args.no_probe else ConvProbe(pkg._C.conv3x3_kernel_name)
 
     def step(i):
         if use_graph:
@@ -140,7 +143,11 @@ def main():
             trainer.train_iteration(pool[i % len(pool)])
 
     if use_graph:
-        trainer.capture(pool[0], warmup=max(1, args.warmup))
+        try:
+            trainer.capture(pool[0], warmup=max(1, args.warmup))
+        except Exception as e:  # capture is an optimisation, never a requirement
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            use_graph = False
     for i in range(args.warmup):
         step(i)
 
@@ -151,7 +158,7 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    if probe is not None:
+    if probe is not None and not use_graph:
         pkg._C.set_probe(probe)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -159,6 +166,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     pkg._C.set_probe(None)
+    probe_note = "HIP events around each launch during the timed steps"
+    if probe is not None and use_graph:
+        # kernels inside a replayed graph cannot be bracketed by events: run the same K steps once more, eagerly,
+        # with the probe on (same kernels, same shapes, same stream)
+        pkg._C.set_probe(probe)
+        for i in range(args.steps):
+            trainer.train_iteration(pool[i % len(pool)])
+        fence()
+        pkg._C.set_probe(None)
+        probe_note = "HIP events around each launch, eager re-run of the timed steps right after the graph-replayed timing"
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,7 +201,7 @@ def main():
             d = summ[dom]
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                               "launches": d["launches"], "avg_launch_us": d["avg_us"]}
+                               "launches": d["launches"], "avg_launch_us": d["avg_us"], "timing": probe_note}
             tot_f = sum(v["flops"] for v in summ.values())
             tot_s = sum(v["seconds"] for v in summ.values())
             out["conv_family"] = {"tflops": tot_f / tot_s / 1e12, "seconds_per_step": tot_s / args.steps,

@@ -56,6 +56,10 @@ int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, flo
                      int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
                      float slope, float eps, void* stream);
 
+/* name of the kernel template instance ngan_conv3x3_fwd dispatches to for these arguments, as rocprofv3 prints it
+ * (profiling aid: lets bench.py label its HIP-event timings with the same names as the kernel trace) */
+int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, char* buf, int len);
+
 /* weight gradient (ATen convolution_backward, weight part):
  *   gw[co][ci][ky][kx] = scale * sum_{b,y,x} g[b,y,x,co] * resample(x)[b,y+ky-1,x+kx-1,ci]      gw is OIHW
  * workspace: ngan_conv3x3_wgrad_workspace_bytes(...) bytes. */

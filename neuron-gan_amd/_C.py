@@ -49,6 +49,7 @@ NON_STATUS = {
     "ngan_version": ([], ctypes.c_char_p),
     "ngan_last_error": ([], ctypes.c_char_p),
     "ngan_conv3x3_wgrad_workspace_bytes": ([_I, _I, _I, _I, _I], _Z),
+    "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
 }
 
 _lib = None
@@ -127,3 +128,10 @@ def call(name, *args):
 
 def wgrad_workspace_bytes(B, H, W, Cin, Cout) -> int:
     return int(lib().ngan_conv3x3_wgrad_workspace_bytes(B, H, W, Cin, Cout))
+
+
+def conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode) -> str:
+    buf = ctypes.create_string_buffer(128)
+    if lib().ngan_conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, buf, 128) != 0:
+        raise RuntimeError(lib().ngan_last_error().decode())
+    return buf.value.decode()

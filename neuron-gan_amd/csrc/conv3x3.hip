@@ -784,6 +784,23 @@ extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float
     }
 }
 
+extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                                        char* buf, int len) {
+    NGAN_REQUIRE(buf && len > 0, NGAN_ERR_ARG, "conv3x3_kernel_name: bad buffer");
+    NGAN_REQUIRE(N == 16 || N == 32 || N == 64 || N == 128, NGAN_ERR_SHAPE, "conv3x3_kernel_name: N=%d", N);
+    const int mti = N == 16 ? 0 : N == 32 ? 1 : N == 64 ? 2 : 3;
+    const int ci = pick_cfg(mti, B, H, W);
+    if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0)
+        snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
+                 out_mode ? 0 : epilogue, out_mode);
+    else {
+        const TileCfg c = kCfg[mti][ci];
+        snprintf(buf, len, "conv3x3_kernel<%d, %d, %d, %d, %d, %d, %d>", c.mtw, c.wn, c.pgw, c.pcg, out_mode ? 0 : resample,
+                 out_mode ? 0 : epilogue, out_mode);
+    }
+    return NGAN_OK;
+}
+
 extern "C" size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % 16) return 0;
     WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
