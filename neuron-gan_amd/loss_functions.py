@@ -30,14 +30,18 @@ class D_W_loss(nn.Module):
         self.drift_epsilon = drift_epsilon
         self.check_nan = check_nan
 
-    def forward(self, real_images, z=None):
+    def forward(self, real_images, z=None, fake_images=None):
         batch_size, device = real_images.size(0), real_images.device
-        real_images_score = self.discriminator_net(real_images)
+        if fake_images is None:
+            z = _latents(self.generator_net, batch_size, device, z)
+            with torch.no_grad():
+                fake_images = self.generator_net(z)
+        # D(real) and D(fake) share the weights and no op couples samples, so they run as ONE critic pass over the
+        # concatenated batch (the reference makes two calls, loss_functions.py:21, 29; per-sample results are identical)
+        scores = self.discriminator_net(torch.cat([real_images, fake_images], dim=0))
+        real_images_score = scores[:batch_size]
         score_real = real_images_score.mean()
-        z = _latents(self.generator_net, batch_size, device, z)
-        with torch.no_grad():
-            fake_images = self.generator_net(z)
-        score_fake = self.discriminator_net(fake_images).mean()
+        score_fake = scores[batch_size:].mean()
         D_loss = -score_real + score_fake
         if self.check_nan:
             if torch.isnan(score_real):
@@ -74,13 +78,14 @@ class D_grad_pen_loss(nn.Module):
         self.Lambda = Lambda
         self.last_grad_norms = None  # per-sample |grad D| of the last call (monitoring / parity tests)
 
-    def forward(self, real_images, z=None, epsilon=None):
+    def forward(self, real_images, z=None, epsilon=None, x_tilde=None):
         if not self.Lambda > 0:
             return torch.tensor(0)
         batch_size, device = real_images.size(0), real_images.device
-        z_latent = _latents(self.generator_net, batch_size, device, z)
-        with torch.no_grad():
-            x_tilde = self.generator_net(z_latent)
+        if x_tilde is None:
+            z_latent = _latents(self.generator_net, batch_size, device, z)
+            with torch.no_grad():
+                x_tilde = self.generator_net(z_latent)
         if epsilon is None:
             epsilon = torch.rand((batch_size, 1, 1, 1), device=device)
         x_hat = ops.xhat(real_images, x_tilde, epsilon)

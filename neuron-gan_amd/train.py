@@ -222,8 +222,11 @@ class PGGANTrainer:
         b = real.size(0)
         self.flat_d.ensure_grad_views()
         self.flat_d.zero_grad()  # Discriminator_net.zero_grad(), train.py:357
-        loss, s_real, s_fake = self.d_loss(real, z=self._latent(b, z_d))  # train.py:358
-        gp = self.gp_loss(real, z=self._latent(b, z_gp), epsilon=eps)  # train.py:361
+        # the two detached generator passes of the D step (loss_functions.py:26, 167) run as one batch-2b pass
+        with torch.no_grad():
+            fakes = self.G(torch.cat([self._latent(b, z_d), self._latent(b, z_gp)], dim=0))
+        loss, s_real, s_fake = self.d_loss(real, fake_images=fakes[:b])  # train.py:358
+        gp = self.gp_loss(real, x_tilde=fakes[b:], epsilon=eps)  # train.py:361
         loss = loss + gp  # train.py:362
         loss.backward()  # train.py:365
         self._exchange(self.flat_d)
