@@ -44,7 +44,7 @@ class ConvProbe:
 
     def add(self, name, args, e0, e1):
         b, h, w, k, n, resample, epilogue, out_mode = args[5:13]
-        key = self.name_of(b, h, w, k, n, resample, epilogue, out_mode)   # the template instance, as rocprofv3 names it
+        key = self.name_of(b, h, w, k, n, resample, epilogue, out_mode, args[15])   # the template instance, as rocprofv3 names it
         self.records.append((key, 2.0 * 9 * k * n * b * h * w, e0, e1))
 
     def summary(self):

@@ -43,8 +43,15 @@ const char* ngan_last_error(void);
  * into MFMA fragment order and pre-multiplied by the equalised-LR constant `scale` (models.py:201).
  *   mode 0 (forward):  k = Cin, n = Cout.
  *   mode 1 (dgrad):    k = Cout, n = Cin, taps flipped: the same kernel then computes the input gradient.
- * `packed` holds 9*Cin*Cout floats.  Cin and Cout must be multiples of 16. */
-int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int Cin, int mode, float scale, void* stream);
+ * `packed` holds ngan_conv3x3_packed_floats(...) floats.  Cin and Cout must be multiples of 16. */
+int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int Cin, int mode, float scale, int precision,
+                              void* stream);
+/* precision 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32).  precision 1: "bf16x3" -- every fp32 operand is split into
+ * hi = bf16(v), lo = bf16(v - hi) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation (relative error ~1e-5 per product instead of ~1e-7; ~5x the fp32 MFMA rate, which makes these layers
+ * HBM-bound).  It exists for few-channel layers on large images (K, N in {16, 32}); ask before packing / calling: */
+int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision);
+long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision);   /* size of `packed` in floats */
 
 /* y = epilogue(conv3x3(resample(x), packed) + bias)      (models.py:252-268 fused: resample, conv, LReLU, PixelNorm)
  *   x        resample 0: (B,H,W,K)   1: (B,2H,2W,K)   2: (B,H/2,W/2,K)       (H, W: conv/output resolution)
@@ -54,11 +61,12 @@ int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int 
  * K = contraction channels, N = output channels (N <= 128 per call). */
 int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                      int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                     float slope, float eps, void* stream);
+                     float slope, float eps, int precision, void* stream);
 
 /* name of the kernel template instance ngan_conv3x3_fwd dispatches to for these arguments, as rocprofv3 prints it
  * (profiling aid: lets bench.py label its HIP-event timings with the same names as the kernel trace) */
-int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, char* buf, int len);
+int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision,
+                             char* buf, int len);
 
 /* weight gradient (ATen convolution_backward, weight part):
  *   gw[co][ci][ky][kx] = scale * sum_{b,y,x} g[b,y,x,co] * resample(x)[b,y+ky-1,x+kx-1,ci]      gw is OIHW

@@ -15,8 +15,8 @@ _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_floa
 
 # name -> argument types (the trailing void* stream included), mirroring include/ngan.h
 SIGNATURES = {
-    "ngan_conv3x3_pack_weights": [_P, _P, _I, _I, _I, _F, _P],
-    "ngan_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
+    "ngan_conv3x3_pack_weights": [_P, _P, _I, _I, _I, _F, _I, _P],
+    "ngan_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "ngan_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "ngan_lrelu_pixelnorm_fwd": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
     "ngan_lrelu_pixelnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
@@ -49,7 +49,9 @@ NON_STATUS = {
     "ngan_version": ([], ctypes.c_char_p),
     "ngan_last_error": ([], ctypes.c_char_p),
     "ngan_conv3x3_wgrad_workspace_bytes": ([_I, _I, _I, _I, _I], _Z),
-    "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
+    "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
+    "ngan_conv3x3_uses_bf16x3": ([_I, _I, _I, _I, _I, _I, _I], _I),
+    "ngan_conv3x3_packed_floats": ([_I, _I, _I], _L),
 }
 
 _lib = None
@@ -130,8 +132,16 @@ def wgrad_workspace_bytes(B, H, W, Cin, Cout) -> int:
     return int(lib().ngan_conv3x3_wgrad_workspace_bytes(B, H, W, Cin, Cout))
 
 
-def conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode) -> str:
+def conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, precision=0) -> str:
     buf = ctypes.create_string_buffer(128)
-    if lib().ngan_conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, buf, 128) != 0:
+    if lib().ngan_conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, precision, buf, 128) != 0:
         raise RuntimeError(lib().ngan_last_error().decode())
     return buf.value.decode()
+
+
+def conv3x3_uses_bf16x3(B, H, W, K, N, resample, precision) -> int:
+    return int(lib().ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, precision))
+
+
+def conv3x3_packed_floats(cout, cin, precision) -> int:
+    return int(lib().ngan_conv3x3_packed_floats(cout, cin, precision))

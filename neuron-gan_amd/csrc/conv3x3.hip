@@ -70,6 +70,36 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     packed[idx] = v * scale;
 }
 
+// Split-bf16 ("bf16x3") packing for v_mfma_f32_16x16x32_bf16: every weight w*scale is written as hi = bf16(w) and
+// lo = bf16(w - hi).  Layout [step][n-tile mt][part hi/lo][lane][8]; lane l holds n = 16*mt + (l & 15) and
+// k = 8*(l >> 4) + j.  K = 16: a step is a PAIR of taps (k < 16 -> tap 2*step, k >= 16 -> tap 2*step + 1; the 10th
+// tap is zero padding), 5 steps.  K = 32: a step is one tap, k = input channel, 9 steps.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ packed, int Cout, int Cin,
+                                           int mode, float scale) {
+    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    const int MT = N / 16, nstep = K == 16 ? 5 : 9;
+    const long total = (long)nstep * MT * 2 * 64 * 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, part = (idx >> 9) & 1;
+    long r = idx >> 10;
+    const int mt = r % MT;
+    const int step = r / MT;
+    const int n = mt * 16 + (lane & 15), kk = 8 * (lane >> 4) + j;
+    const int tap = K == 16 ? 2 * step + (kk >> 4) : step;
+    const int k = K == 16 ? (kk & 15) : kk;
+    float v = 0.f;
+    if (tap < 9) {
+        if (mode == 0) v = w[((long)n * Cin + k) * 9 + tap];
+        else           v = w[((long)k * Cin + n) * 9 + (8 - tap)];
+    }
+    v *= scale;
+    const __bf16 hi = (__bf16)v;
+    packed[idx] = part == 0 ? hi : (__bf16)(v - (float)hi);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward / dgrad kernel.  256 threads = 4 waves arranged WP (along pixels) x WN (along output channels).
 // A wave owns PGW pixel groups (16 consecutive pixels of one tile row each) x MTW 16-channel tiles; the block
@@ -253,16 +283,39 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 // tile t+1 before the MFMAs of tile t, so every CU always has a tile's worth of loads in flight.
 // Bilinear x2 input: the low-resolution source patch (6x18 pixels) is staged once and expanded LDS -> LDS.
 // ---------------------------------------------------------------------------------------------------------
+// float index of the hi half of (16-channel group g, channel quad c4) of tile pixel (ty, tx) in the split-bf16 image
+template <int KG, int PLANE, int LP>
+__device__ __forceinline__ int bf16_slot(int g, int c4, int ty, int tx) {
+    const int slot = (KG == 1 ? (c4 >> 1) : (2 * g + (c4 >> 1))) ^ (((tx >> 2) & 1) << 1);
+    return (ty * LP + tx) * 16 + slot * 4 + (c4 & 1) * 2;
+}
+
+// write 4 fp32 channels as 4 hi + 4 lo bf16 (8 bytes each); idx = bf16_slot(...)
+template <int KG, int PLANE>
+__device__ __forceinline__ void st_split(float* tile, int idx, float4 v) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+    *reinterpret_cast<bf16x4*>(&tile[idx]) = hi;
+    *reinterpret_cast<bf16x4*>(&tile[KG == 1 ? (idx ^ 8) : (idx + PLANE)]) = lo;
+}
+
 // LDS image of a tile: rows of LP = 40 pixels (>= 34 used), 16 floats per pixel, one plane per 16-channel group.
 // The 16-byte quad c of pixel column X is stored at quad (c ^ 2*((X >> 2) & 1)): with that rotation the 16-lane groups of
 // a ds_read_b128 (lanes = 16 consecutive pixels x 4 quads) touch 16 distinct 16-byte slots of a 256-byte bank row
 // (conflict-free; the plain layout is 2-way).  A row pitch that is a multiple of 8 pixels keeps the rotation a
 // function of the column only, so the read address is 3 registers (one per dx) + immediates.
-template <int MTW, int KG, int RES, int EPI, int OUTMODE>
-__global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
+// PREC = 1: split-bf16 arithmetic (3 x v_mfma_f32_16x16x32_bf16 per fp32 product group, fp32 accumulate): the fp32 input
+// is split into hi/lo bf16 halves while the tile is staged; LDS image per pixel (K = 16): [hi c0-7][hi c8-15][lo c0-7]
+// [lo c8-15] (16 B each, same 64 B and the same rotation as the fp32 image); K = 32: plane 0 = hi, plane 1 = lo.
+template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
+__global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
     constexpr int THc = 8, TWc = 32, HH_ = THc + 2, HW_ = TWc + 2, NPIX = HH_ * HW_, LP = 40;
     constexpr int PH = THc / 2 + 2, PW = TWc / 2 + 2, NPP = PH * PW;
-    constexpr int W_ELEMS = 9 * KG * MTW * 256, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int NSTEP = KG == 1 ? 5 : 9;   // bf16x3: K = 32 contraction steps per tile
+    constexpr int W_ELEMS = PREC ? NSTEP * MTW * 2 * 256 : 9 * KG * MTW * 256, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
     constexpr int PATCH_ELEMS = RES == NGAN_RESAMPLE_UP2 ? KG * NPP * 16 : 0;
     constexpr int N_SRC = RES == NGAN_RESAMPLE_UP2 ? KG * NPP * 4 : KG * NPIX * 4;   // float4 loads per tile
     constexpr int NST = (N_SRC + 255) / 256;
@@ -297,7 +350,8 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_
             const int pix = (e >> 2) % NPIX, g = (e >> 2) / NPIX;
             const int ty = pix / HW_, tx = pix % HW_;
             s_dy[i] = ty - 1; s_dx[i] = tx - 1; s_ch[i] = g * 16 + c4 * 4;
-            s_lds[i] = g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+            s_lds[i] = PREC ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx)
+                            : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
         }
     }
     // expansion descriptors (bilinear): destination LDS index, the 4 patch taps and whether the item exists
@@ -310,7 +364,8 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_
             const int c4 = e & 3, pix = (e >> 2) % NPIX, g = (e >> 2) / NPIX;
             const int ty = pix / HW_, tx = pix % HW_;
             x_ty[i] = e < KG * NPIX * 4 ? ty : -100; x_tx[i] = tx;
-            x_dst[i] = g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+            x_dst[i] = PREC ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx)
+                            : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
             // high-res (ty-1, tx-1) relative to an even tile origin: odd offsets are "even" output rows (2i): taps (i-1, i)
             // patch row index = low-res row - (y0/2 - 1); for offset d = ty-1: even d -> rows d/2, d/2+1 ; odd d -> (d+1)/2, (d+1)/2+1 ... see below
             const int dy = ty - 1, dx = tx - 1;   // in [-1, 8] / [-1, 32]
@@ -322,6 +377,18 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_
     int rd[3];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) rd[dx] = (p + dx) * 16 + ((q ^ ((((p + dx) >> 2) & 1) << 1)) << 2);
+    // bf16x3: per contraction step, this lane's offset of the hi fragment (lo = same ^ 8 floats for K = 16, + PLANE for K = 32)
+    int rs[PREC ? NSTEP : 1];
+    if (PREC) {
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            int tap = KG == 1 ? 2 * st + (q >> 1) : st;
+            if (tap > 8) tap = 8;                                  // zero-weight padding tap: any valid address
+            const int dy = tap / 3, dx = tap % 3;
+            const int slot = (KG == 1 ? (q & 1) : q) ^ ((((p + dx) >> 2) & 1) << 1);
+            rs[st] = (dy * LP + p + dx) * 16 + slot * 4;
+        }
+    }
 
     auto decode = [&](int tt, int& b, int& y0, int& x0) {
         const int txi = tt % a.tiles_x; tt /= a.tiles_x;
@@ -381,12 +448,16 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_
                     float4 bot = f4fma(ld4(r0 + PW * 16 + 16), 1.0f - wx0, f4scale(ld4(r0 + PW * 16), wx0));
                     v = f4fma(bot, 1.0f - wy0, f4scale(top, wy0));
                 }
-                st4(&tile[x_dst[i]], v);
+                if (PREC) st_split<KG, PLANE>(tile, x_dst[i], v);
+                else st4(&tile[x_dst[i]], v);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NST; ++i)
-                if (tid + i * 256 < N_SRC) st4(&tile[s_lds[i]], stg[i]);
+                if (tid + i * 256 < N_SRC) {
+                    if (PREC) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
+                    else st4(&tile[s_lds[i]], stg[i]);
+                }
         }
         __syncthreads();
         const int tn = t + nper;
@@ -397,6 +468,30 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_
         for (int pg = 0; pg < 4; ++pg)
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (PREC) {
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                bf16x8 xh[4], xl[4];
+#pragma unroll
+                for (int pg = 0; pg < 4; ++pg) {
+                    const int row = wave * 2 + (pg >> 1);
+                    const int base = (row * LP + (pg & 1) * 16) * 16 + rs[st];
+                    xh[pg] = *reinterpret_cast<const bf16x8*>(&tile[base]);
+                    xl[pg] = *reinterpret_cast<const bf16x8*>(&tile[KG == 1 ? (base ^ 8) : (base + PLANE)]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wl[((st * MTW + mt) * 2 + 0) * 256 + lane * 4]);
+                    const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&wl[((st * MTW + mt) * 2 + 1) * 256 + lane * 4]);
+#pragma unroll
+                    for (int pg = 0; pg < 4; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[pg], acc[pg][mt], 0, 0, 0);
+#pragma unroll
+                    for (int pg = 0; pg < 4; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[pg], acc[pg][mt], 0, 0, 0);
+#pragma unroll
+                    for (int pg = 0; pg < 4; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[pg], acc[pg][mt], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
@@ -420,6 +515,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_
                             acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i], xv[pg][i], acc[pg][mt], 0, 0, 0);
                 }
             }
+        }
         }
         // ---- epilogue (same math as conv3x3_kernel with WN = 1; reciprocal square root instead of sqrt + divide) ----
         const long img = (long)b * a.H * a.W;
@@ -471,28 +567,39 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? 4 : 2) void conv3x3_persist_
     }
 }
 
-template <int MTW, int KG, int RES, int EPI, int OUTMODE>
+template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 int launch_persist(ConvArgs a, hipStream_t s) {
     a.tiles_x = ngan::ceil_div(a.W, 32);
     a.tiles_y = ngan::ceil_div(a.H, 8);
     const int n_tiles = a.B * a.tiles_x * a.tiles_y;
-    const int lds = 4 * (9 * KG * MTW * 256 + KG * 10 * 40 * 16 + (RES == 2 ? KG * 6 * 18 * 16 : 0));
-    int per_cu = (160 * 1024) / lds;
-    if (per_cu > 4) per_cu = 4;
+    // persistent grid = what is actually resident (registers and LDS both limit it): an over-subscribed static
+    // tile partition would serialise whole workgroups behind each other
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_persist_kernel<MTW, KG, RES, EPI, OUTMODE, PREC>, 256, 0) != hipSuccess || n < 1) n = 1;
+        per_cu = n > 4 ? 4 : n;
+    }
     int grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     grid &= ~7;
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL((conv3x3_persist_kernel<MTW, KG, RES, EPI, OUTMODE>), dim3(grid), dim3(256), 0, s, a, n_tiles);
+    hipLaunchKernelGGL((conv3x3_persist_kernel<MTW, KG, RES, EPI, OUTMODE, PREC>), dim3(grid), dim3(256), 0, s, a, n_tiles);
     return ngan::launch_status("ngan_conv3x3_fwd(persistent)");
 }
 
-template <int MTW, int KG>
-int dispatch_persist(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
-    if (outmode == 1) return launch_persist<MTW, KG, 0, 0, 1>(a, s);
-    if (res == 0) return epi ? launch_persist<MTW, KG, 0, 1, 0>(a, s) : launch_persist<MTW, KG, 0, 0, 0>(a, s);
-    return epi ? launch_persist<MTW, KG, 2, 1, 0>(a, s) : launch_persist<MTW, KG, 2, 0, 0>(a, s);
+template <int MTW, int KG, int PREC>
+int dispatch_persist2(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
+    if (outmode == 1) return launch_persist<MTW, KG, 0, 0, 1, PREC>(a, s);
+    if (res == 0) return epi ? launch_persist<MTW, KG, 0, 1, 0, PREC>(a, s) : launch_persist<MTW, KG, 0, 0, 0, PREC>(a, s);
+    return epi ? launch_persist<MTW, KG, 2, 1, 0, PREC>(a, s) : launch_persist<MTW, KG, 2, 0, 0, PREC>(a, s);
 }
+
+template <int MTW, int KG>
+int dispatch_persist(const ConvArgs& a, int res, int epi, int outmode, int prec, hipStream_t s) {
+    return prec ? dispatch_persist2<MTW, KG, 1>(a, res, epi, outmode, s) : dispatch_persist2<MTW, KG, 0>(a, res, epi, outmode, s);
+}
+
 
 // tile shapes: {MTW, WN, PGW, PCG}.  Per output-channel count, ordered from the largest pixel tile to the smallest.
 struct TileCfg { int mtw, wn, pgw, pcg; };
@@ -520,6 +627,11 @@ int pick_cfg(int mti, int B, int H, int W) {
         if (nwg >= kMinBlocks && waste <= 1.3) return i;
     }
     return 2;
+}
+
+// the persistent kernel (and with it the split-bf16 arithmetic) applies to few-channel layers on large images
+inline bool persist_eligible(int B, int H, int W, int K, int N, int resample) {
+    return N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && pick_cfg(N / 16 - 1, B, H, W) == 0;
 }
 
 template <int MTI, int CI, int RES, int EPI, int OUTMODE>
@@ -741,12 +853,34 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, hipStream_t s)
 
 }  // namespace
 
+extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
+    if (precision == 0) return 9L * Cin * Cout;
+    if (Cout > 32 || Cin > 32) return 0;
+    return 10L * Cout * 32;   // per (k, n) orientation at most 9 steps x 2 parts x 512 bf16 per n-tile; 10*Cout*32 floats covers both
+}
+
+extern "C" int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision) {
+    if (precision != 1 || B <= 0 || H <= 0 || W <= 0) return 0;
+    if (!(N == 16 || N == 32) || !(K == 16 || K == 32)) return 0;
+    return persist_eligible(B, H, W, K, N, resample) ? 1 : 0;
+}
+
 extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int Cin, int mode, float scale,
-                                         void* stream) {
+                                         int precision, void* stream) {
     NGAN_REQUIRE(w_oihw && packed, NGAN_ERR_ARG, "conv3x3_pack_weights: null pointer");
     NGAN_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_pack_weights: Cin=%d, Cout=%d must be positive multiples of 16", Cin, Cout);
     NGAN_REQUIRE(mode == 0 || mode == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: mode %d", mode);
+    NGAN_REQUIRE(precision == 0 || precision == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
+    if (precision == 1) {
+        NGAN_REQUIRE(Cout <= 32 && Cin <= 32, NGAN_ERR_SHAPE, "conv3x3_pack_weights: split-bf16 packing needs Cin, Cout <= 32");
+        const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+        const long tot = (long)(K == 16 ? 5 : 9) * (N / 16) * 2 * 64 * 8;
+        hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(ngan::ceil_div(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                           w_oihw, reinterpret_cast<__bf16*>(packed), Cout, Cin, mode, scale);
+        return ngan::launch_status("ngan_conv3x3_pack_weights(bf16x3)");
+    }
     const long total = 9L * Cin * Cout;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(ngan::ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        w_oihw, packed, Cout, Cin, mode, scale);
@@ -755,8 +889,10 @@ extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int
 
 extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                                 int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                                float slope, float eps, void* stream) {
+                                float slope, float eps, int precision, void* stream) {
     NGAN_REQUIRE(x && packed && y, NGAN_ERR_ARG, "conv3x3_fwd: null pointer");
+    NGAN_REQUIRE(precision == 0 || (precision == 1 && ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, 1)), NGAN_ERR_ARG,
+                 "conv3x3_fwd: precision %d is not available for this shape (ask ngan_conv3x3_uses_bf16x3)", precision);
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_fwd: bad dims B=%d H=%d W=%d", B, H, W);
     NGAN_REQUIRE(K > 0 && K % 16 == 0, NGAN_ERR_SHAPE, "conv3x3_fwd: K=%d must be a positive multiple of 16", K);
     NGAN_REQUIRE(N == 16 || N == 32 || N == 64 || N == 128, NGAN_ERR_SHAPE, "conv3x3_fwd: N=%d must be 16/32/64/128", N);
@@ -769,12 +905,12 @@ extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float
                  "conv3x3_fwd: bilinear x2 needs even H, W");
     ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, 0, 0, slope, eps};
     hipStream_t s = (hipStream_t)stream;
-    if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && pick_cfg(N / 16 - 1, B, H, W) == 0) {
+    if (persist_eligible(B, H, W, K, N, resample)) {
         // large image, few channels: persistent pipelined kernel
-        if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, s)
-                                    : dispatch_persist<1, 2>(a, resample, epilogue, out_mode, s);
-        return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, s)
-                       : dispatch_persist<2, 2>(a, resample, epilogue, out_mode, s);
+        if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, precision, s)
+                                    : dispatch_persist<1, 2>(a, resample, epilogue, out_mode, precision, s);
+        return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, precision, s)
+                       : dispatch_persist<2, 2>(a, resample, epilogue, out_mode, precision, s);
     }
     switch (N / 16) {
         case 1: return dispatch_conv<0>(a, resample, epilogue, out_mode, s);
@@ -785,14 +921,14 @@ extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float
 }
 
 extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                                        char* buf, int len) {
+                                        int precision, char* buf, int len) {
     NGAN_REQUIRE(buf && len > 0, NGAN_ERR_ARG, "conv3x3_kernel_name: bad buffer");
     NGAN_REQUIRE(N == 16 || N == 32 || N == 64 || N == 128, NGAN_ERR_SHAPE, "conv3x3_kernel_name: N=%d", N);
     const int mti = N == 16 ? 0 : N == 32 ? 1 : N == 64 ? 2 : 3;
     const int ci = pick_cfg(mti, B, H, W);
     if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0)
-        snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
-                 out_mode ? 0 : epilogue, out_mode);
+        snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
+                 out_mode ? 0 : epilogue, out_mode, precision);
     else {
         const TileCfg c = kCfg[mti][ci];
         snprintf(buf, len, "conv3x3_kernel<%d, %d, %d, %d, %d, %d, %d>", c.mtw, c.wn, c.pgw, c.pcg, out_mode ? 0 : resample,

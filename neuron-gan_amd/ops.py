@@ -20,7 +20,24 @@ from torch.autograd.function import once_differentiable
 
 from . import _C
 
+import os
+
 RES_NONE, RES_POOL2, RES_UP2 = 0, 1, 2
+# arithmetic of the 3x3 convolutions: "f32" = exact fp32 MFMA everywhere; "bf16x3" = few-channel layers on large images
+# use the split-bf16 kernels (3 bf16 MFMAs per product group, fp32 accumulate, ~1e-5 relative error), the rest stays fp32
+PRECISIONS = {"f32": 0, "bf16x3": 1}
+_conv_precision = PRECISIONS[os.environ.get("NGAN_CONV_PRECISION", "f32")]
+
+
+def set_conv_precision(name):
+    global _conv_precision
+    _conv_precision = PRECISIONS[name]
+    bump_weight_epoch()
+
+
+def get_conv_precision():
+    return [k for k, v in PRECISIONS.items() if v == _conv_precision][0]
+
 PIXELNORM_EPS = 1e-8  # models.py:105 of the reference
 
 # ---------------------------------------------------------------------------------------------------------
@@ -37,9 +54,9 @@ def bump_weight_epoch():
     _pack_cache.clear()
 
 
-def _packed(weight, mode, scale):
+def _packed(weight, mode, scale, precision=0):
     # identity is checked through a weak reference: a data_ptr alone can be recycled by the allocator
-    key = (id(weight), weight.data_ptr(), weight._version, mode, float(scale), _weight_epoch)
+    key = (id(weight), weight.data_ptr(), weight._version, mode, float(scale), precision, _weight_epoch)
     hit = _pack_cache.get(key)
     if hit is not None and hit[0]() is weight:
         return hit[1]
@@ -47,8 +64,11 @@ def _packed(weight, mode, scale):
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
-    packed = torch.empty(9 * cin * cout, device=weight.device, dtype=torch.float32)
-    _C.call("ngan_conv3x3_pack_weights", w, packed, cout, cin, mode, float(scale))
+    n_packed = _C.conv3x3_packed_floats(cout, cin, precision)
+    if n_packed <= 0:
+        raise RuntimeError(f"conv3x3: unsupported channel counts Cin={cin}, Cout={cout} (must be positive multiples of 16)")
+    packed = torch.empty(n_packed, device=weight.device, dtype=torch.float32)
+    _C.call("ngan_conv3x3_pack_weights", w, packed, cout, cin, mode, float(scale), precision)
     _pack_cache[key] = (weakref.ref(weight), packed)
     return packed
 
@@ -88,8 +108,9 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope):
         raise RuntimeError(f"conv3x3: input has {x.shape[3]} channels, weight expects {cin}")
     y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32)
     rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if epilogue else None
-    _C.call("ngan_conv3x3_fwd", x, _packed(weight, 0, scale), bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0,
-            float(slope), PIXELNORM_EPS)
+    prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
+    _C.call("ngan_conv3x3_fwd", x, _packed(weight, 0, scale, prec), bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0,
+            float(slope), PIXELNORM_EPS, prec)
     return y, rn
 
 
@@ -99,13 +120,14 @@ def _run_dgrad(g, weight, resample, scale):
     cin = weight.shape[1]
     if cout != weight.shape[0]:
         raise RuntimeError(f"conv3x3 dgrad: gradient has {cout} channels, weight has {weight.shape[0]} outputs")
-    packed = _packed(weight, 1, scale)
+    prec = _C.conv3x3_uses_bf16x3(b, h, w, cout, cin, 0, _conv_precision)
+    packed = _packed(weight, 1, scale, prec)
     if resample == RES_POOL2:
         gx = torch.empty((b, 2 * h, 2 * w, cin), device=g.device, dtype=torch.float32)
-        _C.call("ngan_conv3x3_fwd", g, packed, None, gx, None, b, h, w, cout, cin, 0, 0, 1, 0.0, 0.0)
+        _C.call("ngan_conv3x3_fwd", g, packed, None, gx, None, b, h, w, cout, cin, 0, 0, 1, 0.0, 0.0, prec)
         return gx
     gfull = torch.empty((b, h, w, cin), device=g.device, dtype=torch.float32)
-    _C.call("ngan_conv3x3_fwd", g, packed, None, gfull, None, b, h, w, cout, cin, 0, 0, 0, 0.0, 0.0)
+    _C.call("ngan_conv3x3_fwd", g, packed, None, gfull, None, b, h, w, cout, cin, 0, 0, 0, 0.0, 0.0, prec)
     if resample == RES_UP2:
         gx = torch.empty((b, h // 2, w // 2, cin), device=g.device, dtype=torch.float32)
         _C.call("ngan_up2_adjoint", gfull, gx, b, h // 2, w // 2, cin)

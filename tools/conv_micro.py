@@ -20,6 +20,7 @@ ap.add_argument("--res", type=int, default=0)
 ap.add_argument("--epi", type=int, default=1)
 ap.add_argument("--out", type=int, default=0)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--prec", type=int, default=0)
 a = ap.parse_args()
 pkg = load_package()
 C, ops = pkg._C, pkg.ops
@@ -29,11 +30,12 @@ x = torch.randn(a.B, hin, win, a.K, device=dev)
 w = torch.randn(a.N, a.K, 3, 3, device=dev)
 flops = 2.0 * 9 * a.K * a.N * a.B * a.H * a.W
 if a.op == "fwd":
-    packed = ops._packed(w, 0, 0.1)
+    prec = C.conv3x3_uses_bf16x3(a.B, a.H, a.W, a.K, a.N, a.res, a.prec)
+    packed = ops._packed(w, 0, 0.1, prec)
     oh, ow = (2 * a.H, 2 * a.W) if a.out else (a.H, a.W)
     y = torch.empty(a.B, oh, ow, a.N, device=dev)
     rn = torch.empty(a.B, a.H, a.W, device=dev)
-    run = lambda: C.call("ngan_conv3x3_fwd", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.res, a.epi, a.out, 0.2, 1e-8)
+    run = lambda: C.call("ngan_conv3x3_fwd", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.res, a.epi, a.out, 0.2, 1e-8, prec)
 else:
     g = torch.randn(a.B, a.H, a.W, a.N, device=dev)
     gw = torch.empty(a.N, a.K, 3, 3, device=dev)
@@ -49,4 +51,4 @@ for _ in range(a.iters):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / a.iters
-print(f"{a.op} B{a.B} {a.H}x{a.W} K{a.K} N{a.N} res{a.res} epi{a.epi} out{a.out}: {us:.1f} us  {flops / us / 1e6:.1f} TFLOP/s")
+print(f"prec{a.prec} {a.op} B{a.B} {a.H}x{a.W} K{a.K} N{a.N} res{a.res} epi{a.epi} out{a.out}: {us:.1f} us  {flops / us / 1e6:.1f} TFLOP/s")
