@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256, (COT * CIT == 1) ? 4 : 2) void wgrad_kernel(Wg
 // out[(co*K + ci)*9 + tap] = scale * sum_parts slab[part][slice][tap][co_l][ci_l]; 16 outputs x 16 part-lanes per block
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
                                                            int nparts, int nslices, int n_ci_slices, int CO_S, int CI_S,
-                                                           int K, float scale) {
+                                                           int K, float scale, int accumulate) {
     __shared__ float red[256];
     const int slab = 9 * CO_S * CI_S;
     const long M = (long)nslices * slab;
@@ -814,7 +814,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int co_l = r % CO_S;
         const int tap = r / CO_S;
         const int co = (slice / n_ci_slices) * CO_S + co_l, ci = (slice % n_ci_slices) * CI_S + ci_l;
-        gw[((long)co * K + ci) * 9 + tap] = s * scale;
+        float* o = gw + ((long)co * K + ci) * 9 + tap;
+        *o = accumulate ? fmaf(s, scale, *o) : s * scale;
     }
 }
 
@@ -944,7 +945,8 @@ extern "C" size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci
 }
 
 extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
-                                  int B, int H, int W, int Cin, int Cout, int resample, float scale, void* stream) {
+                                  int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate,
+                                  void* stream) {
     NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "conv3x3_wgrad: null pointer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_wgrad: bad dims B=%d H=%d W=%d", B, H, W);
     NGAN_REQUIRE(Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
@@ -963,6 +965,6 @@ extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, flo
     if (st) return st;
     const long M = (long)p.nslices * 9 * p.co_s * p.ci_s;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ngan::ceil_div(M, 16)), dim3(256), 0, s, workspace, gw, p.nwx,
-                       p.nslices, p.n_ci_slices, p.co_s, p.ci_s, Cin, scale);
+                       p.nslices, p.n_ci_slices, p.co_s, p.ci_s, Cin, scale, accumulate);
     return ngan::launch_status("ngan_conv3x3_wgrad(reduce)");
 }

@@ -9,16 +9,20 @@ namespace {
 
 constexpr int BCH = 16;  // batch rows handled per block
 
-// One block per output pixel p and batch chunk.  Row j = c*S + p of W (K floats) is read by one wave.
-// out_l[b][c] collects the pre-activations of the pixel, then LeakyReLU + PixelNorm over c.
+// One block per output pixel p and batch chunk of 16.  out[b][c] = sum_k z[b][k] * W[c*S + p][k] is a 16 x C x K GEMM:
+// v_mfma_f32_16x16x4_f32 with A = z (16 samples x 4 k, from LDS) and B = W^T (4 k x 16 weight rows, streamed from HBM
+// straight into registers, 16 B per lane; the k-order inside a 16-wide group is permuted identically on both operands).
+// The accumulator holds sample 4q+r of weight row (channel) l & 15; LeakyReLU + PixelNorm over the C channels of the
+// pixel then go through LDS.
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ z, const float* __restrict__ Wt,
                                                          float* __restrict__ y, float* __restrict__ rn, int B, int K,
                                                          int S, int C, float scale, float slope, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* z_l = sm;                 // BCH * K
+    float* z_l = sm;                 // BCH * K   (row b, k contiguous)
     float* out_l = sm + BCH * K;     // BCH * C
     float* r_l = out_l + BCH * C;    // BCH
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
     const int p = blockIdx.x, b0 = blockIdx.y * BCH;
     const int nb = min(BCH, B - b0);
     for (int e = tid; e < BCH * K; e += 256) {
@@ -26,21 +30,25 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         z_l[e] = bb < nb ? z[(long)(b0 + bb) * K + (e - bb * K)] * scale : 0.f;   // weight_scale * x, models.py:241
     }
     __syncthreads();
-    const int K4 = K >> 2;
-    for (int c = wave; c < C; c += 4) {
-        const float* wrow = Wt + ((long)c * S + p) * K;
-        float part[BCH];
-#pragma unroll
-        for (int bb = 0; bb < BCH; ++bb) part[bb] = 0.f;
-        for (int k4 = lane; k4 < K4; k4 += 64) {
-            const float4 wv = ld4(wrow + k4 * 4);
-#pragma unroll
-            for (int bb = 0; bb < BCH; ++bb) part[bb] += f4dot(wv, ld4(z_l + bb * K + k4 * 4));
+    const int ntile = (C + 15) >> 4, ksteps = K >> 4;
+    for (int ct = wave; ct < ntile; ct += 4) {
+        const int c = ct * 16 + j;
+        const float* wrow = Wt + ((long)min(c, C - 1) * S + p) * K + q * 4;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ksteps; ++s) {
+            const float4 wv = ld4(wrow + s * 16);                      // W[row c][16s + 4q .. +3]
+            const float4 zv = ld4(z_l + j * K + s * 16 + q * 4);       // z[sample j][16s + 4q .. +3]
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.x, wv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.y, wv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.z, wv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.w, wv.w, acc, 0, 0, 0);
         }
+        if (c < C) {
 #pragma unroll
-        for (int bb = 0; bb < BCH; ++bb) {
-            const float s = group_sum<64>(part[bb]);
-            if (lane == bb) out_l[bb * C + c] = s > 0.f ? s : slope * s;
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[r];
+                out_l[(4 * q + r) * C + c] = v > 0.f ? v : slope * v;
+            }
         }
     }
     __syncthreads();
@@ -144,7 +152,7 @@ int ew_blocks(long n) {
 extern "C" int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* y, float* rnorm, int B, int K, int S, int C,
                                         float scale, float slope, float eps, void* stream) {
     NGAN_REQUIRE(z && Wt && y && rnorm, NGAN_ERR_ARG, "linear_lrelu_pn_fwd: null pointer");
-    NGAN_REQUIRE(B > 0 && K > 0 && K % 4 == 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: B=%d K=%d S=%d C=%d unsupported",
+    NGAN_REQUIRE(B > 0 && K > 0 && K % 16 == 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: B=%d K=%d (multiple of 16) S=%d C=%d unsupported",
                  B, K, S, C);
     const size_t lds = (size_t)(BCH * K + BCH * C + BCH) * sizeof(float);
     NGAN_REQUIRE(lds <= 64 * 1024, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: K=%d C=%d need %zu B of LDS", K, C, lds);

@@ -287,6 +287,37 @@ __global__ void up2_adjoint_kernel(const float* __restrict__ gy, float* __restri
     }
 }
 
+// float4 version (C % 4 == 0): one thread per (low-res pixel, channel quad)
+__global__ __launch_bounds__(256) void up2_adjoint_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int h,
+                                                              int w, int C) {
+    const int Q = C >> 2;
+    const long total = (long)B * h * w * Q;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % Q);
+        long r = i / Q;
+        const int X = (int)(r % w); r /= w;
+        const int Y = (int)(r % h);
+        const int b = (int)(r / h);
+        const float* base = gy + (long)b * 4 * h * w * C + c4 * 4;
+        float4 s = f4zero();
+#pragma unroll
+        for (int dy = -1; dy <= 2; ++dy) {
+            const int RY = 2 * Y + dy;
+            const float wy = up2_adj_w(Y, RY, h);
+            if (wy == 0.f) continue;
+            float4 rowsum = f4zero();
+#pragma unroll
+            for (int dx = -1; dx <= 2; ++dx) {
+                const int RX = 2 * X + dx;
+                const float wx = up2_adj_w(X, RX, w);
+                if (wx != 0.f) rowsum = f4fma(ld4(base + ((long)RY * (2 * w) + RX) * C), wx, rowsum);
+            }
+            s = f4fma(rowsum, wy, s);
+        }
+        st4(gx + i * 4, s);
+    }
+}
+
 __global__ void pool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C) {
     const long total = (long)B * h * w * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -485,7 +516,18 @@ extern "C" int ngan_to_image_bwd(const float* g, const float* t, const float* x,
         return ngan::launch_status(#NAME);                                                                     \
     }
 RESAMPLE_API(ngan_up2_fwd, up2_fwd_kernel, (long)B * 4 * h * w * C)
-RESAMPLE_API(ngan_up2_adjoint, up2_adjoint_kernel, (long)B * h * w * C)
+extern "C" int ngan_up2_adjoint(const float* a, float* o, int B, int h, int w, int C, void* stream) {
+    NGAN_REQUIRE(a && o, NGAN_ERR_ARG, "ngan_up2_adjoint: null pointer");
+    NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, "ngan_up2_adjoint: bad dims %d %d %d %d", B, h, w, C);
+    const long total = (long)B * h * w * C;
+    if (C % 4 == 0) {
+        long nb = (total / 4 + 255) / 256;
+        hipLaunchKernelGGL(up2_adjoint_vec_kernel, dim3((int)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
+    } else {
+        hipLaunchKernelGGL(up2_adjoint_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
+    }
+    return ngan::launch_status("ngan_up2_adjoint");
+}
 RESAMPLE_API(ngan_pool2_fwd, pool2_fwd_kernel, (long)B * h * w * C)
 RESAMPLE_API(ngan_pool2_adjoint, pool2_adjoint_kernel, (long)B * 4 * h * w * C)
 

@@ -135,13 +135,21 @@ def _run_dgrad(g, weight, resample, scale):
     return gfull
 
 
-def _run_wgrad(x, g, resample, scale):
+def _run_wgrad(x, g, resample, scale, accumulate_into=None):
     b, h, w, cout = g.shape
     cin = x.shape[3]
-    gw = torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
+    gw = accumulate_into if accumulate_into is not None else torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
     ws = torch.empty(_C.wgrad_workspace_bytes(b, h, w, cin, cout) // 4, device=g.device, dtype=torch.float32)
-    _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale))
+    _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 1 if accumulate_into is not None else 0)
     return gw
+
+
+def _accumulates_in_place(weight):
+    """True when a weight gradient can be added straight into weight.grad by the kernel: a plain (not create_graph)
+    backward into a leaf parameter whose .grad buffer already exists (the step driver's flat gradient views).
+    Saves one tiny elementwise add launch per weight per backward (autograd's AccumulateGrad)."""
+    return (not torch.is_grad_enabled()) and weight.is_leaf and weight.grad is not None and weight.grad.is_contiguous() \
+        and weight.grad.dtype == torch.float32
 
 
 def _channel_sum(g):
@@ -179,7 +187,12 @@ class ConvLReLUPN(Function):
             gy = torch.zeros_like(y)
         gc = LReLUPNBwd.apply(gy, gr, y, rn, slope)
         gx = ConvDgrad.apply(gc, weight, resample, scale) if ctx.needs_input_grad[0] else None
-        gw = ConvWgrad.apply(x, gc, resample, scale) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            if _accumulates_in_place(weight):
+                _run_wgrad(x, _c(gc), resample, scale, accumulate_into=weight.grad)   # weight.grad += ..., returns None to autograd
+            else:
+                gw = ConvWgrad.apply(x, gc, resample, scale)
         gb = ChannelSum.apply(gc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None, None
 
@@ -221,7 +234,12 @@ class ConvDgrad(Function):
         g, weight = ctx.saved_tensors
         resample, scale = ctx.cfg
         gg = Conv.apply(h, weight, None, resample, scale) if ctx.needs_input_grad[0] else None
-        gw = ConvWgrad.apply(h, g, resample, scale) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            if _accumulates_in_place(weight):
+                _run_wgrad(_c(h), g, resample, scale, accumulate_into=weight.grad)
+            else:
+                gw = ConvWgrad.apply(h, g, resample, scale)
         return gg, gw, None, None
 
 
