@@ -70,10 +70,12 @@ int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, in
 
 /* weight gradient (ATen convolution_backward, weight part):
  *   gw[co][ci][ky][kx] = scale * sum_{b,y,x} g[b,y,x,co] * resample(x)[b,y+ky-1,x+kx-1,ci]      gw is OIHW
+ * precision 1 requests the split-bf16 kernel (used when the image is at least 32 pixels wide, else exact fp32).
  * accumulate != 0: gw += ... (adds into an existing gradient buffer).  workspace: ngan_conv3x3_wgrad_workspace_bytes(...) bytes. */
 size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
-                       int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate, void* stream);
+                       int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate, int precision,
+                       void* stream);
 
 /* ---- LeakyReLU -> PixelNorm: models.py:263-264, 118-126 (ATen leaky_relu, pow, mean, sqrt, div) ---------------
  * fwd:    a = lrelu(c + bias); r = sqrt(mean_c(a^2) + eps); y = a / r

@@ -17,7 +17,7 @@ _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_floa
 SIGNATURES = {
     "ngan_conv3x3_pack_weights": [_P, _P, _I, _I, _I, _F, _I, _P],
     "ngan_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
-    "ngan_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ngan_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "ngan_lrelu_pixelnorm_fwd": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
     "ngan_lrelu_pixelnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "ngan_lrelu_pixelnorm_bwdbwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P],

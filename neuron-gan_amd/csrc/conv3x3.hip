@@ -790,6 +790,145 @@ __global__ __launch_bounds__(256, (COT * CIT == 1) ? 4 : 2) void wgrad_kernel(Wg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Split-bf16 weight gradient.  The contraction index is the PIXEL, so an MFMA operand (v_mfma_f32_16x16x32_bf16: 8
+// consecutive k per lane) needs 8 pixels of ONE channel per lane -- the transpose of the channels-last image.  The tile
+// is therefore staged pixel-major as bf16 hi/lo planes of 16 channels ([part][plane][pixel][16], 32-byte rows) and the
+// operands are fetched with ds_read_b64_tr_b16, which hands lane i of a 16-lane group column (channel) i of 4 rows
+// (pixels).  One k-step = one tile row of 32 pixels; lane group kq takes pixels 4kq..4kq+3 and 16+4kq..16+4kq+3 (the
+// same permutation on both operands), so each 32-lane half of a read touches 256 contiguous bytes: conflict-free,
+// and the dx tap shift is just a different row address (no alignment constraint).
+// ---------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* base_lo16, const __bf16* base_hi16) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)base_lo16);
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)base_hi16);
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+template <int COT, int CIT, int RES>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
+    constexpr int TW = 32, TH = 8, HALO_H = TH + 2, HALO_W = TW + 2, G_PIX = TH * TW, X_PIX = HALO_H * HALO_W;
+    constexpr int CO_S = COT * 16, CI_S = CIT * 16;
+    constexpr int WO = COT * CIT, WR = 4 / WO, RPW = TH / WR;
+    constexpr int G_E = 2 * COT * G_PIX * 16, X_E = 2 * CIT * X_PIX * 16;       // bf16 elements
+    constexpr int RED_BYTES = 4 * 9 * 64 * 16;
+    constexpr int SMEM_BYTES = (G_E + X_E) * 2 > RED_BYTES ? (G_E + X_E) * 2 : RED_BYTES;
+    constexpr int NG = G_PIX * (CO_S / 4) / 256, NXI = X_PIX * (CI_S / 4), NX = (NXI + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+    __bf16* g_img = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* x_img = g_img + G_E;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+    const int wo = wave % WO, wr = wave / WO;
+    const int cot = wo / CIT, cit = wo % CIT;
+    const int slice = blockIdx.y;
+    const int co0 = (slice / a.n_ci_slices) * CO_S, ci0 = (slice % a.n_ci_slices) * CI_S;
+
+    int g_r[NG], g_c[NG], g_ch[NG], g_l[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int e = tid + i * 256;
+        const int pix = e / (CO_S / 4), c4 = e % (CO_S / 4);
+        g_r[i] = pix / TW; g_c[i] = pix % TW; g_ch[i] = co0 + c4 * 4;
+        g_l[i] = ((c4 >> 2) * G_PIX + pix) * 16 + (c4 & 3) * 4;                 // hi part; lo = + COT*G_PIX*16
+    }
+    int x_r[NX], x_c[NX], x_ch[NX], x_l[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int e = tid + i * 256;
+        const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
+        x_r[i] = e < NXI ? pix / HALO_W - 1 : -1000; x_c[i] = pix % HALO_W - 1; x_ch[i] = ci0 + c4 * 4;
+        x_l[i] = ((c4 >> 2) * X_PIX + pix) * 16 + (c4 & 3) * 4;
+    }
+    // this lane's transposing-read offsets (bf16 elements) inside one plane: pixel 4kq + qq (second read: + 16), channels 4pp..
+    const int tr0 = (4 * kq + qq) * 16 + 4 * pp;
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 gst[NG], xst[NX];
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int txi = t % a.tiles_x; t /= a.tiles_x;
+        const int tyi = t % a.tiles_y;
+        const int b = t / a.tiles_y;
+        const int y0 = tyi * TH, x0 = txi * TW;
+        const float* gb = a.g + (long)b * a.H * a.W * a.N;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int gy = y0 + g_r[i], gx = x0 + g_c[i];
+            gst[i] = (gy < a.H && gx < a.W) ? ld4(gb + ((long)gy * a.W + gx) * a.N + g_ch[i]) : f4zero();
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            xst[i] = x_r[i] > -1000 ? load_resampled<RES>(a.x, b, y0 + x_r[i], x0 + x_c[i], x_ch[i], a.H, a.W, a.K) : f4zero();
+    };
+    auto split_store = [&](__bf16* img, int idx, int lo_off, float4 v) {
+        bf16x4 hi, lo;
+        hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+        lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+        lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+        *reinterpret_cast<bf16x4*>(img + idx) = hi;
+        *reinterpret_cast<bf16x4*>(img + idx + lo_off) = lo;
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.n_tiles) issue(tile);
+    while (tile < a.n_tiles) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NG; ++i) split_store(g_img, g_l[i], COT * G_PIX * 16, gst[i]);
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (x_r[i] > -1000) split_store(x_img, x_l[i], CIT * X_PIX * 16, xst[i]);
+        __syncthreads();
+        const int tn = tile + gridDim.x;
+        if (tn < a.n_tiles) issue(tn);
+        const __bf16* gh = g_img + cot * G_PIX * 16 + tr0;
+        const __bf16* gl = gh + COT * G_PIX * 16;
+        const __bf16* xh = x_img + cit * X_PIX * 16 + tr0;
+        const __bf16* xl = xh + CIT * X_PIX * 16;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wr * RPW + rr;
+            const bf16x8 ah = tr_frag(gh + r * TW * 16, gh + (r * TW + 16) * 16);
+            const bf16x8 al = tr_frag(gl + r * TW * 16, gl + (r * TW + 16) * 16);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+                const int xo = ((r + dy) * HALO_W + dx) * 16;
+                const bf16x8 bh = tr_frag(xh + xo, xh + xo + 256);
+                const bf16x8 bl = tr_frag(xl + xo, xl + xo + 256);
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[tap], 0, 0, 0);
+            }
+        }
+        tile = tn;
+    }
+
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem_raw);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        red[(wave * 9 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    float* slab = a.partial + ((long)blockIdx.x * gridDim.y + slice) * (9 * CO_S * CI_S);
+    for (int e = tid; e < WO * 9 * 64; e += 256) {
+        const int l = e & 63, t = (e >> 6) % 9, o = (e >> 6) / 9;
+        float4 v = red[(o * 9 + t) * 64 + l];
+#pragma unroll
+        for (int k = 1; k < WR; ++k) v = f4add(v, red[((k * WO + o) * 9 + t) * 64 + l]);
+        const int ci_l = (o % CIT) * 16 + (l & 15), co_l = (o / CIT) * 16 + 4 * (l >> 4);
+        float* op = slab + ((long)t * CO_S + co_l) * CI_S + ci_l;
+        op[0] = v.x; op[CI_S] = v.y; op[2 * CI_S] = v.z; op[3 * CI_S] = v.w;
+    }
+}
+
 // out[(co*K + ci)*9 + tap] = scale * sum_parts slab[part][slice][tap][co_l][ci_l]; 16 outputs x 16 part-lanes per block
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
                                                            int nparts, int nslices, int n_ci_slices, int CO_S, int CI_S,
@@ -838,8 +977,14 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 }
 
 template <int COT, int CIT>
-int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, hipStream_t s) {
+int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision, hipStream_t s) {
     dim3 grid(p.nwx, p.nslices);
+    if (precision == 1 && p.tw == 32) {
+        if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0>), grid, dim3(256), 0, s, a);
+        else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2>), grid, dim3(256), 0, s, a);
+        return ngan::launch_status("ngan_conv3x3_wgrad(bf16x3)");
+    }
     if (p.tw == 32) {
         if (res == 0) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 0, 32>), grid, dim3(256), 0, s, a);
         else if (res == 1) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 1, 32>), grid, dim3(256), 0, s, a);
@@ -946,7 +1091,7 @@ extern "C" size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci
 
 extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
                                   int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate,
-                                  void* stream) {
+                                  int precision, void* stream) {
     NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "conv3x3_wgrad: null pointer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_wgrad: bad dims B=%d H=%d W=%d", B, H, W);
     NGAN_REQUIRE(Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
@@ -958,10 +1103,11 @@ extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, flo
     WgradArgs a{x, g, workspace, B, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.n_tiles, p.n_ci_slices};
     hipStream_t s = (hipStream_t)stream;
     int st;
-    if (p.co_s == 32 && p.ci_s == 32) st = launch_wgrad<2, 2>(a, p, resample, s);
-    else if (p.co_s == 32) st = launch_wgrad<2, 1>(a, p, resample, s);
-    else if (p.ci_s == 32) st = launch_wgrad<1, 2>(a, p, resample, s);
-    else st = launch_wgrad<1, 1>(a, p, resample, s);
+    NGAN_REQUIRE(precision == 0 || precision == 1, NGAN_ERR_ARG, "conv3x3_wgrad: precision %d", precision);
+    if (p.co_s == 32 && p.ci_s == 32) st = launch_wgrad<2, 2>(a, p, resample, precision, s);
+    else if (p.co_s == 32) st = launch_wgrad<2, 1>(a, p, resample, precision, s);
+    else if (p.ci_s == 32) st = launch_wgrad<1, 2>(a, p, resample, precision, s);
+    else st = launch_wgrad<1, 1>(a, p, resample, precision, s);
     if (st) return st;
     const long M = (long)p.nslices * 9 * p.co_s * p.ci_s;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ngan::ceil_div(M, 16)), dim3(256), 0, s, workspace, gw, p.nwx,

@@ -140,7 +140,8 @@ def _run_wgrad(x, g, resample, scale, accumulate_into=None):
     cin = x.shape[3]
     gw = accumulate_into if accumulate_into is not None else torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
     ws = torch.empty(_C.wgrad_workspace_bytes(b, h, w, cin, cout) // 4, device=g.device, dtype=torch.float32)
-    _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 1 if accumulate_into is not None else 0)
+    _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 1 if accumulate_into is not None else 0,
+            _conv_precision)
     return gw
 
 

@@ -40,7 +40,7 @@ else:
     g = torch.randn(a.B, a.H, a.W, a.N, device=dev)
     gw = torch.empty(a.N, a.K, 3, 3, device=dev)
     ws = torch.empty(C.wgrad_workspace_bytes(a.B, a.H, a.W, a.K, a.N) // 4, device=dev)
-    run = lambda: C.call("ngan_conv3x3_wgrad", x, g, gw, ws, a.B, a.H, a.W, a.K, a.N, a.res, 0.1, 0)
+    run = lambda: C.call("ngan_conv3x3_wgrad", x, g, gw, ws, a.B, a.H, a.W, a.K, a.N, a.res, 0.1, 0, a.prec)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
