@@ -29,6 +29,7 @@ from __graft_entry__ import load_package  # noqa: E402
 G_WIDTHS = [128, 64, 32, 32, 16, 16]
 D_WIDTHS = [16, 16, 32, 32, 64, 128]
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (about 6.3 TB/s is achievable with a float4 copy)
 
 
 class ConvProbe:
@@ -45,17 +46,24 @@ class ConvProbe:
     def add(self, name, args, e0, e1):
         b, h, w, k, n, resample, epilogue, out_mode = args[5:13]
         key = self.name_of(b, h, w, k, n, resample, epilogue, out_mode, args[15])   # the template instance, as rocprofv3 names it
-        self.records.append((key, 2.0 * 9 * k * n * b * h * w, e0, e1))
+        # algorithmic work of one launch: 2*9*K*N flop per output pixel; bytes = the input read once
+        # (K channels per source pixel; 1/4 of the pixels for bilinear input, 4x for pooled), the output written once
+        # (4x the pixels for the pool-adjoint store) and the per-pixel norm when the epilogue produces it
+        pix = b * h * w
+        src = pix * (4 if resample == 1 else 0.25 if resample == 2 else 1)
+        nbytes = 4.0 * (src * k + pix * n * (4 if out_mode else 1) + (pix if epilogue else 0))
+        self.records.append((key, 2.0 * 9 * k * n * pix, nbytes, e0, e1))
 
     def summary(self):
         per = {}
-        for key, flops, e0, e1 in self.records:
-            d = per.setdefault(key, [0, 0.0, 0.0])
+        for key, flops, nbytes, e0, e1 in self.records:
+            d = per.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
             d[2] += e0.elapsed_time(e1) * 1e-3
-        return {k: {"launches": v[0], "flops": v[1], "seconds": v[2], "avg_us": v[2] / v[0] * 1e6,
-                    "tflops": v[1] / v[2] / 1e12} for k, v in per.items() if v[2] > 0}
+            d[3] += nbytes
+        return {k: {"launches": v[0], "flops": v[1], "seconds": v[2], "avg_us": v[2] / v[0] * 1e6, "tflops": v[1] / v[2] / 1e12,
+                    "gbs": v[3] / v[2] / 1e9} for k, v in per.items() if v[2] > 0}
 
 
 def build_nets(pkg, res, alpha, device):
@@ -108,6 +116,9 @@ def main():
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay a captured HIP graph, 0: eager, -1: auto")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
+                    help="conv arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate) where available")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient all-reduce even with one rank (path test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="do not time the dominant kernel with HIP events")
     args = ap.parse_args()
@@ -120,20 +131,23 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     pkg = load_package()
     pkg._C.lib()
+    pkg.ops.set_conv_precision(args.precision)
     G, D = build_nets(pkg, args.res, args.alpha, device)
     trainer = pkg.train.PGGANTrainer(G, D, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001,
                                      device_latents=True)
+    trainer.force_exchange = args.force_dist
     torch.manual_seed(123 + rank)
     pool = [(torch.rand(args.batch, 1, args.res, args.res) * 2 - 1).to(device) for _ in range(4)]
     torch.cuda.manual_seed(1000 + rank)
 
     # launch mode: HIP-graph replay of the whole iteration on one GPU (captured once), eager under torchrun
-    use_graph = args.graph == 1 or (args.graph == -1 and world == 1)
+    use_graph = args.graph == 1 or (args.graph == -1 and not use_dist)
     probe = None if args.no_probe else ConvProbe(pkg._C.conv3x3_kernel_name)
 
     def step(i):
@@ -153,7 +167,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +190,7 @@ def main():
         fence()
         pkg._C.set_probe(None)
         probe_note = "HIP events around each launch, eager re-run of the timed steps right after the graph-replayed timing"
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -189,30 +203,38 @@ def main():
         w_alg = 5 * fg + 14 * fd  # algorithmic flops per image per iteration
         out = {"metric": "images/sec (G+D step incl. GP) at 512x512", "value": value, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.precision == "f32" else "f32 storage/accumulate; 3x3 convs on split-bf16 MFMA (bf16x3, hi+lo operands)",
+               "data": "synthetic",
                "config": {"workload": f"{args.res}x{args.res} stage, alpha={args.alpha}, batch {args.batch}/GPU, WGAN-GP lambda=10, "
                                       f"drift 0.001, n_critic=1, Adam(1e-4, 0.5, 0.999), widths G{G_WIDTHS} D{D_WIDTHS}",
                           "global_batch": args.batch * world, "resolution": args.res, "parallelism": f"dp{world}",
-                          "launch": "hip-graph replay" if use_graph else "eager"},
+                          "launch": "hip-graph replay" if use_graph else "eager", "conv_precision": args.precision},
                "step_tflops": value * w_alg / 1e12, "step_frac_of_fp32_mfma_peak": value * w_alg / 1e12 / world / PEAK_FP32_MFMA_TFLOPS}
         if probe is not None and probe.records:
             summ = probe.summary()
             dom = max(summ, key=lambda k: summ[k]["seconds"])
             d = summ[dom]
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                               "launches": d["launches"], "avg_launch_us": d["avg_us"], "timing": probe_note}
+            if dom.rstrip(">").endswith(", 1"):   # split-bf16 instance: ~5x the fp32 MFMA rate, so HBM is the binding roof
+                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": None, "launches": d["launches"],
+                                   "avg_launch_us": d["avg_us"], "timing": probe_note,
+                                   "fp32_equivalent_tflops": d["tflops"]}
+            else:
+                out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                   "launches": d["launches"], "avg_launch_us": d["avg_us"], "timing": probe_note}
             tot_f = sum(v["flops"] for v in summ.values())
             tot_s = sum(v["seconds"] for v in summ.values())
             out["conv_family"] = {"tflops": tot_f / tot_s / 1e12, "seconds_per_step": tot_s / args.steps,
-                                  "instances": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2),
+                                  "instances": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
                                                     "launches_per_step": v["launches"] / args.steps} for k, v in summ.items()}}
         else:
             out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.res, args.alpha, sample_batch=min(args.batch, 4))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -113,13 +113,13 @@ class FusedAdam:
         ops.bump_weight_epoch()  # packed conv weights are stale now
 
 
-def exchange_gradients(flat: FlatParams, world: int, group=None):
+def exchange_gradients(flat: FlatParams, world: int, group=None, force: bool = False):
     """Data-parallel gradient exchange: ONE all-reduce(SUM) over the net's flat gradient buffer (RCCL over xGMI on the
     GPU; gloo in the CPU tests).  The 1/world factor is not applied here -- it is folded into the fused Adam kernel
     (`FusedAdam.set_grad_scale`), so the averaged gradient never makes an extra pass through HBM.  No op couples
     samples (PixelNorm is per pixel, every loss is a batch mean), so N ranks x batch b with this exchange equals
     one rank x batch N*b up to fp32 summation order."""
-    if world > 1:
+    if world > 1 or force:   # force: exercise the collective on a one-rank group (bench.py --force-dist)
         dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)
 
 
@@ -178,6 +178,7 @@ class PGGANTrainer:
         if self.world > 1:
             self.opt_g.set_grad_scale(1.0 / self.world)
             self.opt_d.set_grad_scale(1.0 / self.world)
+        self.force_exchange = False
         self.refresh_stage()
         self._graph = None
         ops.bump_weight_epoch()
@@ -216,7 +217,7 @@ class PGGANTrainer:
         return sample_latent_vec((batch, self.G.latent_dim), device=self.device)
 
     def _exchange(self, flat):
-        exchange_gradients(flat, self.world, self.group)
+        exchange_gradients(flat, self.world, self.group, force=self.force_exchange)
 
     def d_step(self, real, z_d=None, z_gp=None, eps=None):
         b = real.size(0)
