@@ -147,7 +147,7 @@ def main():
     torch.cuda.manual_seed(1000 + rank)
 
     # launch mode: HIP-graph replay of the whole iteration on one GPU (captured once), eager under torchrun
-    use_graph = args.graph == 1 or (args.graph == -1 and not use_dist)
+    use_graph = args.graph != 0   # one graph on a single GPU; three graphs with eager all-reduces between them under torchrun
     probe = None if args.no_probe else ConvProbe(pkg._C.conv3x3_kernel_name)
 
     def step(i):
@@ -209,7 +209,7 @@ def main():
                "config": {"workload": f"{args.res}x{args.res} stage, alpha={args.alpha}, batch {args.batch}/GPU, WGAN-GP lambda=10, "
                                       f"drift 0.001, n_critic=1, Adam(1e-4, 0.5, 0.999), widths G{G_WIDTHS} D{D_WIDTHS}",
                           "global_batch": args.batch * world, "resolution": args.res, "parallelism": f"dp{world}",
-                          "launch": "hip-graph replay" if use_graph else "eager", "conv_precision": args.precision},
+                          "launch": ("hip-graph replay" + (" (3 segments, eager all-reduce between)" if use_dist else "")) if use_graph else "eager", "conv_precision": args.precision},
                "step_tflops": value * w_alg / 1e12, "step_frac_of_fp32_mfma_peak": value * w_alg / 1e12 / world / PEAK_FP32_MFMA_TFLOPS}
         if probe is not None and probe.records:
             summ = probe.summary()

@@ -219,7 +219,8 @@ class PGGANTrainer:
     def _exchange(self, flat):
         exchange_gradients(flat, self.world, self.group, force=self.force_exchange)
 
-    def d_step(self, real, z_d=None, z_gp=None, eps=None):
+    def d_compute(self, real, z_d=None, z_gp=None, eps=None):
+        """D half-step up to (and including) the backward pass: gradients end up in flat_d.grad."""
         b = real.size(0)
         self.flat_d.ensure_grad_views()
         self.flat_d.zero_grad()  # Discriminator_net.zero_grad(), train.py:357
@@ -230,11 +231,15 @@ class PGGANTrainer:
         gp = self.gp_loss(real, x_tilde=fakes[b:], epsilon=eps)  # train.py:361
         loss = loss + gp  # train.py:362
         loss.backward()  # train.py:365
-        self._exchange(self.flat_d)
-        self.opt_d.step()  # train.py:366
         return {"D_loss": loss.detach(), "score_real": s_real.detach(), "score_fake": s_fake.detach(), "D_grad_pen": gp.detach()}
 
-    def g_step(self, real, z=None):
+    def d_step(self, real, z_d=None, z_gp=None, eps=None):
+        stats = self.d_compute(real, z_d, z_gp, eps)
+        self._exchange(self.flat_d)
+        self.opt_d.step()  # train.py:366
+        return stats
+
+    def g_compute(self, real, z=None):
         b = real.size(0)
         self.flat_g.ensure_grad_views()
         self.flat_g.zero_grad()  # Generator_net.zero_grad(), train.py:375
@@ -247,9 +252,13 @@ class PGGANTrainer:
         finally:
             for p in d_params:
                 p.requires_grad_(True)
+        return {"G_loss": loss.detach()}
+
+    def g_step(self, real, z=None):
+        stats = self.g_compute(real, z)
         self._exchange(self.flat_g)
         self.opt_g.step()  # train.py:385
-        return {"G_loss": loss.detach()}
+        return stats
 
     def train_iteration(self, real, z_d=None, z_gp=None, eps=None, z_g=None):
         stats = {}
@@ -260,10 +269,16 @@ class PGGANTrainer:
 
     # ---- HIP-graph capture of a whole iteration ---------------------------------------------------------------
     def capture(self, real_example, warmup=3):
-        """Capture `train_iteration` for this batch shape into a HIP graph (latents and epsilon drawn on the GPU inside
-        the graph).  Afterwards `replay(real)` copies `real` into the static input and launches the graph."""
+        """Capture `train_iteration` for this batch shape into HIP graphs (latents and epsilon drawn on the GPU inside
+        the graph).  Afterwards `replay(real)` copies `real` into the static input and launches them.
+        One GPU: one graph for the whole iteration.  Data parallel: three graphs -- [D forward/backward],
+        [D Adam, G forward/backward], [G Adam] -- with the two gradient all-reduces issued eagerly between them, so no
+        collective is ever captured."""
         if not self.device_latents:
             raise RuntimeError("graph capture needs device_latents=True (CPU-drawn latents cannot be replayed)")
+        segmented = self.world > 1 or self.force_exchange
+        if segmented and self.n_critic != 1:
+            raise RuntimeError("segmented (data-parallel) capture supports n_critic = 1")
         self._static_real = real_example.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -273,17 +288,38 @@ class PGGANTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.bump_weight_epoch()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._static_stats = self.train_iteration(self._static_real)
-        self._graph = graph
-        ops.bump_weight_epoch()  # drop packed-weight buffers that live in the graph's private pool
-        return graph
+        if not segmented:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._static_stats = self.train_iteration(self._static_real)
+            self._graph = [graph]
+        else:
+            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                stats = self.d_compute(self._static_real)
+            self._exchange(self.flat_d)
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self.opt_d.step()
+                stats.update(self.g_compute(self._static_real))
+            self._exchange(self.flat_g)
+            with torch.cuda.graph(gc, pool=ga.pool()):
+                self.opt_g.step()
+            self._static_stats = stats
+            self._graph = [ga, gb, gc]
+        ops.bump_weight_epoch()  # drop packed-weight buffers that live in the graphs' private pool
+        return self._graph
 
     def replay(self, real=None):
         if self._graph is None:
             raise RuntimeError("call capture() first (and again after every growth event)")
         if real is not None:
             self._static_real.copy_(real, non_blocking=True)
-        self._graph.replay()
+        if len(self._graph) == 1:
+            self._graph[0].replay()
+        else:
+            self._graph[0].replay()
+            self._exchange(self.flat_d)
+            self._graph[1].replay()
+            self._exchange(self.flat_g)
+            self._graph[2].replay()
         return self._static_stats

@@ -29,3 +29,11 @@ def ngan():
     """The product package (directory `neuron-gan_amd/`, imported as `neuron_gan_amd`)."""
     from __graft_entry__ import load_package
     return load_package()
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_precision(request, ngan):
+    """Run a GPU parity test under both conv arithmetic modes: exact fp32 MFMA and split-bf16 (same tolerances)."""
+    ngan.ops.set_conv_precision(request.param)
+    yield request.param
+    ngan.ops.set_conv_precision("f32")

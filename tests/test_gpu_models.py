@@ -56,7 +56,7 @@ def adam_close(got, want, lr):
 
 
 @pytest.mark.parametrize("name", SMALL)
-def test_small_nets_match_reference(ngan, name):
+def test_small_nets_match_reference(ngan, name, conv_precision):
     fix = load_golden(name)
     G, D = build_small(ngan, fix)
     with torch.no_grad():
@@ -88,7 +88,7 @@ FULL = ["full_C1", "full_C2", "full_C3", "full_C4"]
 
 
 @pytest.mark.parametrize("name", FULL)
-def test_full_width_pins(ngan, name):
+def test_full_width_pins(ngan, name, conv_precision):
     """BASELINE.json configs C1..C4: weights from torch.manual_seed(1) (same constructors, same order as the
     reference), reals from seed 123, latents / epsilon from the fixture."""
     fix = load_golden(name)

@@ -86,11 +86,15 @@ CONV_CASES = [
     (16, 16, 16, 64, 64, 2, False),    # bilinear input, 64 channels
     # ... and the 8x32 tile with many channels per wave
     (1, 256, 256, 16, 64, 0, False), (1, 256, 256, 16, 128, 0, True),
+    # persistent kernels (few channels, >= 256 tiles of 8x32): every (K, N) in {16, 32}^2, plain / bilinear input, bias
+    (2, 128, 256, 16, 16, 0, True), (2, 128, 256, 32, 16, 0, False), (2, 128, 256, 16, 32, 0, False), (2, 128, 256, 32, 32, 0, True),
+    (2, 128, 256, 16, 16, 2, False), (2, 128, 256, 32, 16, 2, False), (2, 128, 256, 32, 32, 2, False),
+    (1, 200, 328, 16, 16, 0, False),   # ragged right / bottom edges on the persistent path
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_lrelu_pn_all_orders(ngan, case):
+def test_conv_lrelu_pn_all_orders(ngan, case, conv_precision):
     B, H, W, Cin, Cout, res, use_bias = case
     ops = ngan.ops
     torch.manual_seed(hash(case) % 1000)
@@ -112,7 +116,7 @@ def test_conv_lrelu_pn_all_orders(ngan, case):
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 16, 32, 0, True), (1, 8, 16, 32, 16, 1, False), (1, 8, 8, 16, 16, 2, False)])
-def test_conv_raw_all_orders(ngan, case):
+def test_conv_raw_all_orders(ngan, case, conv_precision):
     B, H, W, Cin, Cout, res, use_bias = case
     ops = ngan.ops
     torch.manual_seed(11)
