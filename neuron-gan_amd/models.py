@@ -354,10 +354,47 @@ class _ProgressiveNet(nn.Module):
             self.increase_resolution()
             self.advance_transition(alpha if self.image_size == res else 1.0)
 
+    def _tag_parameters(self):
+        """state_dict names change when a block moves from conv_block_list into layers; the construction-time name is a
+        stable identity for per-parameter optimiser state."""
+        for name, p in self.named_parameters():
+            p._ngan_name = name
+
     def _saved_attr_names(self, extra):
         names = ['LeakyReLU_neg_slope', 'N_colors', 'N_features_per_layer', 'N_layers', 'N_layers_max', 'image_size',
                  'image_size_init', 'image_size_max', 'training'] + extra
         return sorted(names) + ['alpha']
+
+
+def _drop_legacy_entries(state_dict, list_prefix, n_drop, from_start):
+    """Old-format checkpoints keep already-merged entries of a ModuleList (reference models.py:38-63): drop `n_drop` of them
+    from one end and renumber the rest when they are dropped from the start."""
+    idx = sorted({int(k.split('.')[1]) for k in state_dict if k.startswith(list_prefix + '.')})
+    if not idx or n_drop <= 0:
+        return state_dict
+    assert n_drop <= len(idx), 'Cannot remove more than {} layers'.format(len(idx))
+    dropped = set(idx[:n_drop] if from_start else idx[len(idx) - n_drop:])
+    out = type(state_dict)()
+    for k, v in state_dict.items():
+        if k.startswith(list_prefix + '.'):
+            parts = k.split('.')
+            i = int(parts[1])
+            if i in dropped:
+                continue
+            if from_start:
+                parts[1] = str(i - n_drop)
+            k = '.'.join(parts)
+        out[k] = v
+    return out
+
+
+def _drop_prefix(state_dict, prefix):
+    return type(state_dict)((k, v) for k, v in state_dict.items() if not k.startswith(prefix + '.'))
+
+
+def _count_list_entries(state_dict, list_prefix):
+    idx = {int(k.split('.')[1]) for k in state_dict if k.startswith(list_prefix + '.')}
+    return max(idx) + 1 if idx else 0
 
 
 class Generator_PG(_ProgressiveNet):
@@ -399,6 +436,7 @@ class Generator_PG(_ProgressiveNet):
         self.ToIm = self.ToIm_list.pop(0)
         self.upsample = Interpolate(scale_factor=2, mode='bilinear')
         self.saved_attrs = self._saved_attr_names(['latent_dim'])
+        self._tag_parameters()
 
     def forward(self, x):
         h = run_layers(self.layers, x)
@@ -413,6 +451,32 @@ class Generator_PG(_ProgressiveNet):
     def _merge_pending_block(self):
         self.layers.append(self.conv_block_list.pop(0))
         self.ToIm = self.ToIm_list.pop(0)
+
+    @classmethod
+    def from_state_dict(cls, filename, device=torch.device('cpu'), verbose=True):
+        """Rebuild a generator from a checkpoint written by `Checkpointer` (reference models.py:394-444), including
+        checkpoints in the older layout that still carry merged ToIm_list / conv_block_list entries."""
+        from .utils import load_checkpoint_dict
+        saved = load_checkpoint_dict(filename, device)
+        attrs = saved['Generator_attrs']
+        ctor = {k: attrs[k] for k in ('N_features_per_layer', 'image_size_init', 'LeakyReLU_neg_slope', 'N_colors') if k in attrs}
+        if 'latent_dim' in attrs:
+            ctor['latent_dim'] = attrs['latent_dim']
+        obj = cls(**ctor)
+        obj.set_resolution(attrs['image_size'], float(attrs['alpha']))
+        state = saved['Generator_state']
+        n_toim = _count_list_entries(state, 'ToIm_list')
+        if n_toim > len(obj.ToIm_list):
+            if verbose:
+                print('Warning! Loaded state dict in old format. Keys will be removed to match the new format.')
+            state = _drop_legacy_entries(state, 'ToIm_list', n_toim - len(obj.ToIm_list), from_start=True)
+            state = _drop_legacy_entries(state, 'conv_block_list',
+                                         _count_list_entries(state, 'conv_block_list') - len(obj.conv_block_list), from_start=True)
+            state = _drop_prefix(_drop_prefix(state, 'ToIm_prev'), 'last_conv_block')
+        obj.load_state_dict(state)
+        if verbose:
+            print('Loaded training state from {}'.format(filename))
+        return obj
 
 
 class Discriminator_PG(_ProgressiveNet):
@@ -450,6 +514,7 @@ class Discriminator_PG(_ProgressiveNet):
         self.FromIm = self.FromIm_list.pop(-1)
         self.downsample = Interpolate(scale_factor=0.5, mode='bilinear')
         self.saved_attrs = self._saved_attr_names([])
+        self._tag_parameters()
 
     def forward(self, x):
         x = to_nhwc(x)
@@ -476,3 +541,26 @@ class Discriminator_PG(_ProgressiveNet):
     def _merge_pending_block(self):
         self.layers.insert(0, self.conv_block_list.pop(-1))
         self.FromIm = self.FromIm_list.pop(-1)
+
+    @classmethod
+    def from_state_dict(cls, filename, device=torch.device('cpu'), verbose=True):
+        """Rebuild a critic from a checkpoint (reference models.py:566-616), old layout included."""
+        from .utils import load_checkpoint_dict
+        saved = load_checkpoint_dict(filename, device)
+        attrs = saved['Discriminator_attrs']
+        ctor = {k: attrs[k] for k in ('N_features_per_layer', 'image_size_init', 'LeakyReLU_neg_slope', 'N_colors') if k in attrs}
+        obj = cls(**ctor)
+        obj.set_resolution(attrs['image_size'], float(attrs['alpha']))
+        state = saved['Discriminator_state']
+        n_from = _count_list_entries(state, 'FromIm_list')
+        if n_from > len(obj.FromIm_list):
+            if verbose:
+                print('Warning! Loaded state dict in old format. Keys will be removed to match the new format.')
+            state = _drop_legacy_entries(state, 'FromIm_list', n_from - len(obj.FromIm_list), from_start=False)
+            state = _drop_legacy_entries(state, 'conv_block_list',
+                                         _count_list_entries(state, 'conv_block_list') - len(obj.conv_block_list), from_start=False)
+            state = _drop_prefix(_drop_prefix(state, 'FromIm_prev'), 'first_conv_block')
+        obj.load_state_dict(state)
+        if verbose:
+            print('Loaded training state from {}'.format(filename))
+        return obj

@@ -34,7 +34,7 @@ class FlatParams:
 
     def __init__(self, net: torch.nn.Module):
         self.params = list(net.parameters())
-        self.names = [n for n, _ in net.named_parameters()]
+        self.names = [getattr(p, "_ngan_name", n) for n, p in net.named_parameters()]   # stable across growth stages
         assert self.params, "network has no parameters"
         dev = self.params[0].device  # CPU is allowed for host-logic tests; the fused Adam kernel itself needs the GPU
         offs, total = [], 0
@@ -267,6 +267,31 @@ class PGGANTrainer:
         stats.update(self.g_step(real, z_g))
         return stats
 
+    # ---- optimiser state for checkpoints (optional extra key; the reference saves none) ---------------------------
+    def optimizer_state(self):
+        out = {}
+        for tag, flat, opt in (("G", self.flat_g, self.opt_g), ("D", self.flat_d, self.opt_d)):
+            out[tag] = {"names": list(flat.names), "lr": opt.param_groups[0]["lr"],
+                        "step": flat.seg_step.detach().cpu().clone(),
+                        "exp_avg": {n: flat.exp_avg[o:o + p.numel()].detach().cpu().clone().view(p.shape)
+                                    for n, p, o in zip(flat.names, flat.params, flat.offsets)},
+                        "exp_avg_sq": {n: flat.exp_avg_sq[o:o + p.numel()].detach().cpu().clone().view(p.shape)
+                                       for n, p, o in zip(flat.names, flat.params, flat.offsets)}}
+        return out
+
+    def load_optimizer_state(self, state):
+        for tag, flat, opt in (("G", self.flat_g, self.opt_g), ("D", self.flat_d, self.opt_d)):
+            st = state[tag]
+            saved_step = dict(zip(st["names"], st["step"].tolist()))
+            steps = flat.seg_step.detach().cpu().clone()
+            for i, (n, p, o) in enumerate(zip(flat.names, flat.params, flat.offsets)):
+                if n in st["exp_avg"] and tuple(st["exp_avg"][n].shape) == tuple(p.shape):
+                    flat.exp_avg[o:o + p.numel()].copy_(st["exp_avg"][n].reshape(-1))
+                    flat.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"][n].reshape(-1))
+                    steps[i] = saved_step.get(n, 0.0)
+            flat.seg_step.copy_(steps)
+            opt.set_lr(st["lr"])
+
     # ---- HIP-graph capture of a whole iteration ---------------------------------------------------------------
     def capture(self, real_example, warmup=3):
         """Capture `train_iteration` for this batch shape into HIP graphs (latents and epsilon drawn on the GPU inside
@@ -323,3 +348,227 @@ class PGGANTrainer:
             self._exchange(self.flat_g)
             self._graph[2].replay()
         return self._static_stats
+
+
+# =====================================================================================================================
+# Epoch-level driver and command line: the reference's train.py as functions instead of module-level code.
+# Out of scope and therefore absent: the PNG dataset with PIL/skimage augmentations (data/NeuronDataset.py), score plots,
+# gradient-norm histograms, interactive prompts.  Images come from a tensor file or are synthetic.
+# =====================================================================================================================
+class TensorImageDataset(torch.utils.data.Dataset):
+    """Images (N, C, R, R) in [-1, 1] held on the GPU; `set_image_size` serves them at the current stage's resolution by
+    2x2 averaging (the role of NeuronDataset.set_image_size + Resize, data/NeuronDataset.py:112-126)."""
+
+    def __init__(self, images: torch.Tensor):
+        assert images.dim() == 4 and images.shape[-1] == images.shape[-2]
+        self.full = images
+        self.image_size_max = images.shape[-1]
+        self.image_size = self.image_size_max
+        self._cache = {self.image_size_max: images}
+
+    @classmethod
+    def synthetic(cls, n_images, image_size, n_colors=1, device="cpu", seed=123):
+        g = torch.Generator().manual_seed(seed)
+        return cls((torch.rand(n_images, n_colors, image_size, image_size, generator=g) * 2 - 1).to(device))
+
+    def set_image_size(self, size):
+        assert self.image_size_max % size == 0
+        if size not in self._cache:
+            x = self.full
+            while x.shape[-1] > size:
+                x = torch.nn.functional.avg_pool2d(x, 2)
+            self._cache[size] = x
+        self.image_size = size
+
+    def __len__(self):
+        return self.full.shape[0]
+
+    def __getitem__(self, i):
+        return self._cache[self.image_size][i]
+
+
+def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_final=None, use_graph=True, log=print,
+                samples_dir=None):
+    """The reference's epoch loop (train.py:298-451) over a PGGANTrainer.
+    Per epoch: advance alpha / grow (318-333), one pass over the dataset in batches of cfg.batch_size (350-394), sample-weighted
+    epoch means of the monitors (387-398), a status line every 10 epochs (401-422), LR schedule (424-426), loss series (429-432),
+    checkpoint + sample grid every cfg.checkpointing_period epochs (435-443).  The monitors stay on the GPU and are read back one
+    epoch late through pinned memory, so the host never stalls the launch stream; a NaN loss raises ValueError like the
+    reference's loss modules do (loss_functions.py:35-41, 70-72)."""
+    import time
+    if cfg.adapt_critic:
+        raise NotImplementedError("adapt_critic (utils.Calculate_D_steps) is off by default and not part of the hot path")
+    if cfg.sim_loss_lambda > 0:
+        raise NotImplementedError("similarity loss (lambda = 0 by default) is not part of the hot path")
+    G, D = trainer.G, trainer.D
+    dev = trainer.device
+    epoch_final = epoch_final if epoch_final is not None else cfg.N_epochs + 1
+    n_images = len(dataset)
+    names = ["score_real", "score_fake", "D_loss", "G_loss", "D_grad_pen"]
+    pinned = torch.zeros(2, len(names), pin_memory=True)
+    events = [None, None]
+    pending = [None, None]
+    series = {n: [] for n in names}
+    dataset.set_image_size(G.image_size)
+    graph_shape = None
+    start_time = time.time()
+
+    def consume(slot):
+        if events[slot] is None:
+            return
+        events[slot].synchronize()
+        ep = pending[slot]
+        vals = pinned[slot].tolist()
+        events[slot] = None
+        if any(math.isnan(v) for v in vals):
+            raise ValueError(f"NaN loss at epoch {ep}: " + ", ".join(f"{n}={v}" for n, v in zip(names, vals)))
+        for n, v in zip(names, vals):
+            series[n].append(v)
+        if checkpoint is not None and ep - 1 < len(checkpoint.Loss_real):
+            checkpoint.Loss_real[ep - 1], checkpoint.Loss_fake[ep - 1] = vals[0], vals[1]
+            checkpoint.Loss_D[ep - 1], checkpoint.Loss_G[ep - 1] = vals[2], vals[3]
+        if ep % 10 == 0:
+            done = ep - epoch_init
+            log("Epoch:{}, time(s)/iter:{}, lr:{:.4g}, alpha:{: >5.3f}, Res:{}x{}, Loss_real (<D(x)>_x):{: >#7.4g}, "
+                "Loss_fake (<D(G(z))>):{: >#7.4g}, G_loss:{: >#7.4g}, D_loss:{: >#7.4g}, D_grad_pen:{: >#7.4g}".format(
+                    ep, "{:.3f}".format((time.time() - start_time) / done) if done > 0 else "----",
+                    trainer.opt_g.param_groups[0]["lr"], G.alpha_value(), G.image_size, G.image_size, vals[0], vals[1], vals[3],
+                    vals[2], vals[4]))
+
+    for epoch in range(epoch_init, epoch_final):
+        if trainer.start_epoch(epoch, cfg.transit_sch):
+            dataset.set_image_size(G.image_size)
+            graph_shape = None
+        acc = torch.zeros(len(names), device=dev)
+        order = torch.randperm(n_images).tolist()                     # DataLoader(shuffle=True), train.py:153
+        for i in range(0, n_images, cfg.batch_size):
+            images = torch.stack([dataset[j] for j in order[i:i + cfg.batch_size]]).to(dev)
+            b = images.size(0)
+            if use_graph and trainer.device_latents and cfg.n_critic == 1:
+                if graph_shape != tuple(images.shape):
+                    trainer.capture(images, warmup=1)                # (re)capture after growth or a ragged last batch
+                    graph_shape = tuple(images.shape)
+                stats = trainer.replay(images)
+            else:
+                stats = trainer.train_iteration(images)
+            acc += b * torch.stack([stats["score_real"], stats["score_fake"], stats["D_loss"], stats["G_loss"],
+                                    stats["D_grad_pen"].float()])
+        slot = epoch & 1
+        consume(slot)
+        pinned[slot].copy_(acc / n_images, non_blocking=True)
+        events[slot] = torch.cuda.Event()
+        events[slot].record()
+        pending[slot] = epoch
+        consume(slot ^ 1)                                              # the previous epoch's numbers are ready by now
+        lr = lr_schedule(epoch, cfg.learning_rate, cfg.transit_sch, cfg.N_epochs)
+        if lr is not None:
+            trainer.opt_d.set_lr(lr)
+            trainer.opt_g.set_lr(lr)
+        if checkpoint is not None and epoch % cfg.checkpointing_period == 0:
+            consume(slot)
+            checkpoint.lr = trainer.opt_g.param_groups[0]["lr"]
+            checkpoint.save_state(epoch)
+            if samples_dir is not None:
+                from .utils import plot_gen_samples
+                plot_gen_samples(G, N_images=16, seed=0, filename=os.path.join(samples_dir, "Samples_{}_{:d}.png".format(cfg.ID, epoch)))
+    consume(0)
+    consume(1)
+    return series
+
+
+def build_arg_parser():
+    """The reference's flags (train.py:39-91), same names, types and help; defaults are irrelevant because -- as in the
+    reference (train.py:95-104) -- only flags literally present on the command line override the configuration module."""
+    import argparse
+    import uuid
+    p = argparse.ArgumentParser()
+    p.add_argument('--configs', type=str, default='', help='Filename of configurations stored in ./configs')
+    for name in ('root_dir', 'dataset_dir', 'images_dir', 'weights_dir', 'plots_dir', 'weights_init', 'dis_weights'):
+        p.add_argument('--' + name, type=str, default='')
+    p.add_argument('--wgan', action='store_true')
+    p.add_argument('--n_critic', type=int, default=5)
+    p.add_argument('--adapt_critic', action='store_true', default=False)
+    p.add_argument('--unroll_steps', type=int, default=0)
+    p.add_argument('--pggan', action='store_true')
+    p.add_argument('--grad_pen_lambda', type=float, default=0.0)
+    p.add_argument('--transit_sch', type=float, default=[50, 100, 150, 200, 250, 300, 350], nargs='*')
+    p.add_argument('--transit_period', type=int, default=None)
+    p.add_argument('--alpha_step', type=float, default=0.05)
+    p.add_argument('--RMSprop', action='store_true', default=False)
+    p.add_argument('--learning_rate', type=float, default=0.00002)
+    p.add_argument('--batch_size', type=int, default=8)
+    p.add_argument('--N_epochs', type=int, default=1000)
+    p.add_argument('--beta1', type=float, default=0.8)
+    p.add_argument('--sim_loss_lambda', type=float, default=0.0)
+    p.add_argument('--sim_loss_lambda_decay_rate', type=float, default=0.0)
+    p.add_argument('--drift_epsilon', type=float, default=0.001)
+    p.add_argument('--ID', type=str, default=uuid.uuid4().hex[:4])
+    p.add_argument('--resume', action='store_true', default=False)
+    p.add_argument('--seed', type=int, default=1)
+    p.add_argument('--checkpointing_period', type=int, default=100)
+    p.add_argument('--translation', type=float, default=0.0)
+    p.add_argument('--device', type=str, default='cuda', choices=['cpu', 'mps', 'cuda'])
+    p.add_argument('--N_workers', type=int, default=2)
+    p.add_argument('--pin_memory', action='store_true', default=False)
+    # additions of this implementation
+    p.add_argument('--images', type=str, default='', help='.pt / .npy file with the training images (N, C, R, R) in [-1, 1]; '
+                                                          'synthetic uniform images when omitted')
+    p.add_argument('--N_epochs_session', type=int, default=None)
+    return p
+
+
+def main(argv=None):
+    """`python -m neuron_gan_amd.train ...` -- bootstrap of the reference's train.py:94-296, 623-625 for the PGGAN path."""
+    import sys
+    from .configs import config
+    from . import models
+    from .utils import Checkpointer
+    argv = list(sys.argv[1:] if argv is None else argv)
+    options = build_arg_parser().parse_args(argv)
+    given = [a[2:] for a in argv if a.startswith('--') and a not in ('--configs', '--images')]   # train.py:95
+    given = [g for g in given if g in config.configs_name]
+    if options.configs:
+        config.import_configs(options.configs, {a: getattr(options, a) for a in given}, create_dirs=True)
+    else:
+        config.set_configs(**{a: getattr(options, a) for a in given})
+        config.validate_configs(create_dirs=True)
+    if not config.pggan or config.wgan:
+        raise NotImplementedError("only the PGGAN path (pggan=True, wgan=False) is implemented")
+    if config.device != 'cuda':
+        raise RuntimeError("the HIP path needs device='cuda' (there is no CPU fallback)")
+    config.print_configs()
+    torch.manual_seed(config.seed)
+    device = torch.device('cuda:0')
+    n_up = len(config.N_gen_features) - 1
+    if options.images:
+        data = torch.load(options.images) if options.images.endswith('.pt') else torch.from_numpy(np.load(options.images))
+        dataset = TensorImageDataset(data.float().to(device))
+    else:
+        dataset = TensorImageDataset.synthetic(16, config.image_size, config.N_colors, device=device)
+    size_init = dataset.image_size_max // (2 ** n_up)                                       # train.py:162-165
+    G = models.Generator_PG(config.N_gen_features, image_size_init=size_init).to(device)    # train.py:172-175
+    D = models.Discriminator_PG(config.N_dis_features, image_size_init=size_init).to(device)
+    filename = os.path.join(config.weights_dir, 'GenDisc_{}.pth'.format(config.ID))         # train.py:196-197
+    trainer = None
+    checkpoint = Checkpointer(G, D, config.learning_rate, filename, N_epochs=config.N_epochs, device=device, extra_checkpoint_period=1e3)
+    if config.resume and os.path.exists(filename):
+        checkpoint.load_state()
+    elif config.weights_init:
+        checkpoint.load_state(os.path.join(config.weights_dir, config.weights_init))
+    assert G.image_size == D.image_size, 'The generator and discriminator are at different resolution'   # train.py:215-216
+    trainer = PGGANTrainer(G, D, learning_rate=config.learning_rate, beta1=config.beta1, grad_pen_lambda=config.grad_pen_lambda,
+                           drift_epsilon=config.drift_epsilon, n_critic=config.n_critic, alpha_step=config.alpha_step,
+                           device_latents=True)
+    checkpoint.trainer = trainer
+    epoch_init = checkpoint.epoch + 1
+    lr0 = lr_schedule(epoch_init - 1, config.learning_rate, config.transit_sch, config.N_epochs)       # train.py:288-289
+    if lr0 is not None:
+        trainer.opt_d.set_lr(lr0)
+        trainer.opt_g.set_lr(lr0)
+    epoch_final = epoch_init + config.N_epochs_session if config.N_epochs_session else config.N_epochs + 1
+    return pggan_train(trainer, dataset, config, checkpoint=checkpoint, epoch_init=epoch_init, epoch_final=epoch_final,
+                       samples_dir=config.samples_sub_dir)
+
+
+if __name__ == '__main__':
+    main()

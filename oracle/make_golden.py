@@ -221,6 +221,69 @@ def full_fixture(models, config, name):
     np.savez_compressed(os.path.join(OUT, f"full_{name}.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------
+# checkpoint-format fixtures: files in the reference's dictionary layout (utils.py:160-169), written
+# from reference modules, plus what the reference's own from_state_dict (models.py:394-444, 566-616) makes of them
+# ------------------------------------------------------------------------------------------
+def checkpoint_fixtures(models):
+    os.environ["TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD"] = "1"   # the reference calls torch.load without weights_only (torch 1.13)
+    torch.manual_seed(21)
+    # latent_dim stays at the config default: the reference's from_state_dict does not pass it to the constructor
+    G = models.Generator_PG([16, 16, 16], image_size_init=4)
+    D = models.Discriminator_PG([16, 16, 16], image_size_init=4)
+    G.set_resolution(8, 1.0)
+    D.set_resolution(8, 1.0)
+    attrs = lambda m: {a: getattr(m, a) for a in m.saved_attrs}           # utils.get_saved_attrs
+    ck = {"epoch": 7, "Generator_state": G.state_dict(), "Generator_attrs": attrs(G), "Discriminator_state": D.state_dict(),
+          "Discriminator_attrs": attrs(D), "lr": 1e-4, "Loss_real": np.arange(7.0), "Loss_fake": -np.arange(7.0),
+          "Loss_G": np.ones(7), "Loss_D": np.zeros(7)}
+    new_path = os.path.join(OUT, "ref_checkpoint_new.pth")
+    torch.save(ck, new_path)
+    # old layout: merged ToIm_list / conv_block_list (FromIm_list) entries are still present, plus *_prev / *_conv_block modules
+    gs, ds = G.state_dict(), D.state_dict()
+    old_g = type(gs)()
+    for k, v in gs.items():
+        if k.startswith("ToIm_list.") or k.startswith("conv_block_list."):
+            parts = k.split("."); parts[1] = str(int(parts[1]) + 1); k = ".".join(parts)   # one stale entry in front
+        old_g[k] = v
+    old_g["ToIm_list.0.layers.0.weight"] = torch.randn(1, 16, 1, 1)
+    old_g["conv_block_list.0.1.weight"] = torch.randn(16, 16, 3, 3)
+    old_g["conv_block_list.0.4.weight"] = torch.randn(16, 16, 3, 3)
+    old_g["ToIm_prev.layers.0.weight"] = torch.randn(1, 16, 1, 1)
+    old_g["last_conv_block.1.weight"] = torch.randn(16, 16, 3, 3)
+    old_d = type(ds)()
+    for k, v in ds.items():
+        old_d[k] = v
+    n_from = 1 + max(int(k.split(".")[1]) for k in ds if k.startswith("FromIm_list."))
+    n_blk = 1 + max(int(k.split(".")[1]) for k in ds if k.startswith("conv_block_list."))
+    old_d[f"FromIm_list.{n_from}.conv.weight"] = torch.randn(16, 1, 1, 1)     # one stale entry at the end
+    old_d[f"FromIm_list.{n_from}.conv.bias"] = torch.randn(16)
+    old_d[f"conv_block_list.{n_blk}.1.weight"] = torch.randn(16, 16, 3, 3)
+    old_d[f"conv_block_list.{n_blk}.4.weight"] = torch.randn(16, 16, 3, 3)
+    # (the reference's key parser needs a digit in every matched key, models.py:40, so the stale module is written as a list entry)
+    old_d["FromIm_prev.0.conv.weight"] = torch.randn(16, 1, 1, 1)
+    old_d["first_conv_block.1.weight"] = torch.randn(16, 16, 3, 3)
+    ck_old = dict(ck, Generator_state=old_g, Discriminator_state=old_d)
+    old_path = os.path.join(OUT, "ref_checkpoint_old.pth")
+    torch.save(ck_old, old_path)
+    out = {}
+    for tag, path in (("new", new_path), ("old", old_path)):
+        g2 = models.Generator_PG.from_state_dict(path, verbose=False)
+        d2 = models.Discriminator_PG.from_state_dict(path, verbose=False)
+        for k, v in g2.state_dict().items():
+            out[f"{tag}/G/{k}"] = v.numpy()
+        for k, v in d2.state_dict().items():
+            out[f"{tag}/D/{k}"] = v.numpy()
+        out[f"{tag}/meta"] = np.array([g2.image_size, float(g2.alpha), d2.image_size, float(d2.alpha)])
+    torch.manual_seed(3)
+    z = latent(3, 512)
+    x = torch.rand(3, 1, 8, 8) * 2 - 1
+    with torch.no_grad():
+        out["z"], out["x"], out["G_of_z"], out["D_of_x"] = z.numpy(), x.numpy(), G(z).numpy(), D(x).numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_checkpoint_expected.npz"), **out)
+    print("checkpoint fixtures written:", new_path, old_path)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also regenerate the full-width C3/C4 pins (about a minute of CPU)")
@@ -235,6 +298,8 @@ def main():
     for name, res, alpha, warm in small:
         if not only or name in only:
             small_fixture(models, name, res, alpha, warm)
+    if not only or "checkpoint" in only:
+        checkpoint_fixtures(models)
     for name in (["C1", "C2"] + (["C3", "C4"] if args.full else [])):
         if not only or name in only:
             full_fixture(models, config, name)

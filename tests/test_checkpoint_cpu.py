@@ -1,0 +1,72 @@
+"""Checkpoint-format compatibility on the CPU: files in the reference's dictionary layout, written from
+reference modules by oracle/make_golden.py (current layout and a synthesised old layout), must load into the product's nets
+exactly as the reference's own from_state_dict loads them (expected tensors recorded next to the files)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, split_state
+
+
+@pytest.mark.parametrize("tag", ["new", "old"])
+def test_from_state_dict_matches_reference_loader(ngan, tag):
+    exp = load_golden("ref_checkpoint_expected")
+    path = os.path.join(GOLDEN, f"ref_checkpoint_{tag}.pth")
+    G = ngan.models.Generator_PG.from_state_dict(path, verbose=False)
+    D = ngan.models.Discriminator_PG.from_state_dict(path, verbose=False)
+    meta = exp[f"{tag}/meta"]
+    assert (G.image_size, D.image_size) == (int(meta[0]), int(meta[2]))
+    assert abs(G.alpha_value() - meta[1]) < 1e-7 and abs(D.alpha_value() - meta[3]) < 1e-7
+    for net, prefix in ((G, f"{tag}/G/"), (D, f"{tag}/D/")):
+        want = split_state(exp, prefix)
+        got = net.state_dict()
+        assert list(got.keys()) == list(want.keys())
+        for k, v in want.items():
+            assert np.array_equal(got[k].numpy(), v), k
+
+
+def test_checkpointer_writes_the_reference_layout(ngan, tmp_path):
+    ref = torch.load(os.path.join(GOLDEN, "ref_checkpoint_new.pth"), weights_only=False)   # our own fixture file
+    G = ngan.models.Generator_PG([16, 16, 16], image_size_init=4)
+    D = ngan.models.Discriminator_PG([16, 16, 16], image_size_init=4)
+    G.set_resolution(8, 1.0)
+    D.set_resolution(8, 1.0)
+    f = str(tmp_path / "GenDisc_t.pth")
+    ck = ngan.utils.Checkpointer(G, D, 1e-4, f, N_epochs=20, verbose=False, extra_checkpoint_period=1e3)
+    ck.Loss_real[:5] = np.arange(5.0)
+    ck.save_state(5)
+    mine = torch.load(f, weights_only=False)
+    assert set(ref.keys()) <= set(mine.keys())                      # same keys (an optimizer_state key may be added)
+    assert set(mine["Generator_attrs"]) == set(ref["Generator_attrs"]) and set(mine["Discriminator_attrs"]) == set(ref["Discriminator_attrs"])
+    assert list(mine["Generator_state"].keys()) == list(ref["Generator_state"].keys())
+    assert list(mine["Discriminator_state"].keys()) == list(ref["Discriminator_state"].keys())
+    assert mine["epoch"] == 5 and len(mine["Loss_real"]) == 5
+    # resume into fresh nets
+    G2 = ngan.models.Generator_PG([16, 16, 16], image_size_init=4)
+    D2 = ngan.models.Discriminator_PG([16, 16, 16], image_size_init=4)
+    ck2 = ngan.utils.Checkpointer(G2, D2, 1e-4, f, N_epochs=20, verbose=False)
+    ck2.load_state()
+    assert ck2.epoch == 5 and G2.image_size == 8 and list(ck2.Loss_real[:5]) == [0, 1, 2, 3, 4]
+    for a, b in zip(G.state_dict().values(), G2.state_dict().values()):
+        assert torch.equal(a, b)
+    # weights-only load from another file (the reference's --weights_init path)
+    G3 = ngan.models.Generator_PG([16, 16, 16], image_size_init=4)
+    D3 = ngan.models.Discriminator_PG([16, 16, 16], image_size_init=4)
+    ck3 = ngan.utils.Checkpointer(G3, D3, 1e-4, str(tmp_path / "other.pth"), N_epochs=20, verbose=False)
+    ck3.load_state(os.path.join(GOLDEN, "ref_checkpoint_new.pth"))
+    assert ck3.epoch == 0 and G3.image_size == 8
+    assert torch.equal(G3.state_dict()["layers.0.weight"], ref["Generator_state"]["layers.0.weight"])
+
+
+def test_image_grid_and_cli_parser(ngan):
+    grid = ngan.utils.make_image_grid(torch.rand(5, 1, 4, 4), nrow=2)
+    assert tuple(grid.shape) == (1, 3 * 6 + 2, 2 * 6 + 2)
+    p = ngan.train.build_arg_parser()
+    o = p.parse_args(["--pggan", "--grad_pen_lambda", "10", "--batch_size", "4", "--ID", "0042"])
+    assert o.pggan and o.grad_pen_lambda == 10 and o.batch_size == 4 and o.ID == "0042"
+    ds = ngan.train.TensorImageDataset.synthetic(6, 16)
+    ds.set_image_size(4)
+    assert tuple(ds[0].shape) == (1, 4, 4) and len(ds) == 6
+    assert torch.allclose(ds[0], torch.nn.functional.avg_pool2d(ds.full[0:1], 4)[0], atol=1e-6)

@@ -39,11 +39,13 @@ def run_step_losses(ngan, G, D, fix, lam=10.0, drift=0.001, lr=1e-4):
     tr = ngan.train.PGGANTrainer(G, D, learning_rate=lr, beta1=0.5, grad_pen_lambda=lam, drift_epsilon=drift)
     sd = tr.d_step(t("real"), z_d=t("z_d"), z_gp=t("z_gp"), eps=t("eps"))
     fd = tr.flat_d
-    dgrads = {n: p.grad.detach().cpu().numpy().copy() for n, p, a in zip(fd.names, fd.params, fd.active_host) if a}
+    cur_d = {id(p): n for n, p in D.named_parameters()}   # the fixtures use the state_dict names of the current stage
+    cur_g = {id(p): n for n, p in G.named_parameters()}
+    dgrads = {cur_d[id(p)]: p.grad.detach().cpu().numpy().copy() for p, a in zip(fd.params, fd.active_host) if a}
     norms = tr.gp_loss.last_grad_norms.cpu().numpy()
     sg = tr.g_step(t("real"), z=t("z_g"))
     fg = tr.flat_g
-    ggrads = {n: p.grad.detach().cpu().numpy().copy() for n, p, a in zip(fg.names, fg.params, fg.active_host) if a}
+    ggrads = {cur_g[id(p)]: p.grad.detach().cpu().numpy().copy() for p, a in zip(fg.params, fg.active_host) if a}
     scal = np.array([float(sd["D_loss"]), float(sd["score_real"]), float(sd["score_fake"]), float(sd["D_grad_pen"]),
                      float(sg["G_loss"])])
     return scal, norms, dgrads, ggrads

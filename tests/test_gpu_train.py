@@ -1,0 +1,110 @@
+"""GPU tests of the rows next to the hot path: checkpoint format, multi-iteration trajectories of the step
+driver against the CPU oracle, and the epoch-level driver across growth transitions (graph re-capture, resume, samples)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, split_state
+from oracle import pggan_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_reference_checkpoint_runs_on_gpu(ngan):
+    exp = load_golden("ref_checkpoint_expected")
+    G = ngan.models.Generator_PG([16, 16, 16], image_size_init=4).to(DEV)
+    D = ngan.models.Discriminator_PG([16, 16, 16], image_size_init=4).to(DEV)
+    ck = ngan.utils.Checkpointer(G, D, 1e-4, "unused.pth", verbose=False, device=torch.device(DEV))
+    ck.load_state(os.path.join(GOLDEN, "ref_checkpoint_new.pth"))
+    assert G.image_size == 8 and next(G.parameters()).is_cuda
+    with torch.no_grad():
+        img = G(torch.from_numpy(exp["z"]).to(DEV)).cpu().numpy()
+        score = D(torch.from_numpy(exp["x"]).to(DEV)).cpu().numpy()
+    assert rel(img, exp["G_of_z"]) < 1e-4 and rel(score, exp["D_of_x"]) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["small_res8_warm", "small_res16_fade_warm"])
+def test_three_iterations_follow_the_oracle(ngan, name, conv_precision):
+    """Same weights, same injected latents / epsilon / reals for 3 consecutive iterations: the fused-Adam trajectory (flat
+    buffers, per-tensor step counts, packed-weight refresh) must track torch.optim.Adam on the oracle."""
+    fix = load_golden(name)
+    res, alpha, init, latent, batch, _ = fix["meta"]
+    res, batch, latent = int(res), int(batch), int(latent)
+    G = ngan.models.Generator_PG([32, 16, 16], image_size_init=int(init), latent_dim=latent)
+    D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=int(init))
+    G.set_resolution(res, float(alpha))
+    D.set_resolution(res, float(alpha))
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "G/").items()})
+    D.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "D/").items()})
+    pg, pd = O.as_leaf_params(split_state(fix, "G/")), O.as_leaf_params(split_state(fix, "D/"))
+    spec = O.NetSpec(image_size_init=int(init), slope=0.2, alpha=float(alpha))
+    lr = 1e-3
+    og, od = O.make_adam(pg, lr), O.make_adam(pd, lr)
+    tr = ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), learning_rate=lr)
+    torch.manual_seed(99)
+    for it in range(3):
+        x = torch.rand(batch, 1, res, res) * 2 - 1
+        z = [O.sample_latent_vec((batch, latent)) for _ in range(3)]
+        eps = torch.rand(batch, 1, 1, 1)
+        want = O.train_step(pg, spec, pd, spec, og, od, x, z[0], z[1], eps, z[2])
+        got = tr.train_iteration(x.to(DEV), z_d=z[0].to(DEV), z_gp=z[1].to(DEV), eps=eps.to(DEV), z_g=z[2].to(DEV))
+        for k_w, k_g in (("D_loss", "D_loss"), ("score_real", "score_real"), ("score_fake", "score_fake"), ("GP", "D_grad_pen"), ("G_loss", "G_loss")):
+            assert abs(float(got[k_g]) - want[k_w]) < 2e-3 * abs(want[k_w]) + 2e-4, (it, k_w, float(got[k_g]), want[k_w])
+    # after three steps of lr = 1e-3 the weights have moved by ~3e-3; the two trajectories stay together
+    for k, p in G.named_parameters():
+        if k in pg and pg[k].grad is not None:
+            assert float((p.detach().cpu() - pg[k].detach()).abs().max()) < 2e-4, k
+    for k, p in D.named_parameters():
+        if k in pd and pd[k].grad is not None:
+            assert float((p.detach().cpu() - pd[k].detach()).abs().max()) < 2e-4, k
+
+
+def test_epoch_driver_grows_checkpoints_and_resumes(ngan, tmp_path):
+    models, train, utils = ngan.models, ngan.train, ngan.utils
+    cfg = types.SimpleNamespace(adapt_critic=False, sim_loss_lambda=0.0, n_critic=1, batch_size=4, transit_sch=[3, 6], N_epochs=9,
+                                alpha_step=0.5, learning_rate=1e-3, checkpointing_period=4, ID="t001")
+    torch.manual_seed(5)
+    G = models.Generator_PG([32, 16, 16], image_size_init=4, latent_dim=32).to(DEV)
+    D = models.Discriminator_PG([16, 16, 32], image_size_init=4).to(DEV)
+    data = train.TensorImageDataset.synthetic(8, 16, device=DEV)
+    tr = train.PGGANTrainer(G, D, learning_rate=cfg.learning_rate, alpha_step=cfg.alpha_step, device_latents=True)
+    f = str(tmp_path / "GenDisc_t001.pth")
+    ck = utils.Checkpointer(G, D, cfg.learning_rate, f, N_epochs=cfg.N_epochs, verbose=False, device=torch.device(DEV), trainer=tr,
+                            extra_checkpoint_period=1e3)
+    lines = []
+    series = train.pggan_train(tr, data, cfg, checkpoint=ck, epoch_final=cfg.N_epochs + 1, log=lines.append, samples_dir=str(tmp_path))
+    assert all(len(v) == 9 and np.isfinite(v).all() for v in series.values())
+    assert G.image_size == 16 and D.image_size == 16 and G.alpha_value() >= 1 and D.alpha_value() >= 1
+    assert [k for k in G.state_dict() if k.startswith("conv_block_list")] == [] and len(G.layers) == 9
+    assert os.path.exists(f) and os.path.exists(str(tmp_path / "Samples_t001_8.png"))
+    saved = torch.load(f, weights_only=False)
+    assert saved["epoch"] == 8 and "optimizer_state" in saved and len(saved["Loss_real"]) == 8
+    # the blocks that joined late have fewer Adam steps than the stem (torch skips .grad=None tensors)
+    steps = dict(zip(saved["optimizer_state"]["D"]["names"], saved["optimizer_state"]["D"]["step"].tolist()))
+    # (names are the construction-time ones: the critic's conv_block_list.1 joined at 8x8, conv_block_list.0 at 16x16)
+    assert steps["layers.0.weight"] > steps["conv_block_list.1.1.weight"] > steps["conv_block_list.0.1.weight"] > 0
+    # resume into fresh nets + trainer: same weights, same optimiser moments, and training continues
+    G2 = models.Generator_PG([32, 16, 16], image_size_init=4, latent_dim=32).to(DEV)
+    D2 = models.Discriminator_PG([16, 16, 32], image_size_init=4).to(DEV)
+    tr2 = train.PGGANTrainer(G2, D2, learning_rate=cfg.learning_rate, alpha_step=cfg.alpha_step, device_latents=True)
+    ck2 = utils.Checkpointer(G2, D2, cfg.learning_rate, f, N_epochs=cfg.N_epochs, verbose=False, device=torch.device(DEV), trainer=tr2)
+    ck2.load_state()
+    assert ck2.epoch == 8 and G2.image_size == 16
+    for (k, a), b in zip(saved["Generator_state"].items(), G2.state_dict().values()):
+        assert torch.equal(a, b.cpu()), k
+    st2 = tr2.optimizer_state()
+    assert torch.equal(st2["D"]["step"], saved["optimizer_state"]["D"]["step"])
+    assert torch.equal(st2["G"]["exp_avg"]["layers.4.weight"], saved["optimizer_state"]["G"]["exp_avg"]["layers.4.weight"])
+    more = train.pggan_train(tr2, data, cfg, checkpoint=ck2, epoch_init=9, epoch_final=10, log=lines.append)
+    assert len(more["G_loss"]) == 1 and np.isfinite(more["G_loss"][0])
+    grid = utils.plot_gen_samples(G2, N_images=4, seed=0)
+    assert grid.shape[0] == 1 and grid.shape[1] > 2 * 16

@@ -188,9 +188,10 @@ def test_flat_params_and_active_set(ngan):
     for p, off in zip(flat.params, flat.offsets):
         assert p.data_ptr() == flat.flat.data_ptr() + 4 * off and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * off
     act = {id(p) for p in ngan.train.active_parameters(D)}
-    names = {n for n, p in D.named_parameters() if id(p) in act}
+    names = {n for n, p in D.named_parameters() if id(p) in act}   # current (stage-dependent) names
     assert names == {"layers.0.weight", "layers.0.bias", "layers.3.weight", "layers.3.bias", "FromIm.conv.weight", "FromIm.conv.bias",
                      "conv_block_list.1.1.weight", "conv_block_list.1.4.weight", "FromIm_list.1.conv.weight", "FromIm_list.1.conv.bias"}
+    assert "conv_block_list.1.1.weight" in flat.names and "layers.0.weight" in flat.names   # construction-time names
     sd_before = {k: v.clone() for k, v in D.state_dict().items()}
     D.load_state_dict(sd_before)  # in-place copy keeps the views
     assert flat.params[0].data_ptr() == flat.flat.data_ptr()
