@@ -53,6 +53,13 @@ int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int 
 int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision);
 long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision);   /* size of `packed` in floats */
 
+/* Re-pack many weights with ONE launch (after an optimiser step).  `table` is a device array of n_entries records
+ *   { const float* src; float* dst; int Cout, Cin, mode, precision; float scale; int pad; long first; }          (48 bytes)
+ * where `first` is the running sum of ngan_conv3x3_pack_elements(...) over the preceding entries (the unit is one packed
+ * element: a float for precision 0, a bf16 for precision 1) and total_elements is the sum over all entries. */
+long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int precision);
+int ngan_conv3x3_pack_many(const void* table, int n_entries, long total_elements, void* stream);
+
 /* y = epilogue(conv3x3(resample(x), packed) + bias)      (models.py:252-268 fused: resample, conv, LReLU, PixelNorm)
  *   x        resample 0: (B,H,W,K)   1: (B,2H,2W,K)   2: (B,H/2,W/2,K)       (H, W: conv/output resolution)
  *   bias     N floats or NULL

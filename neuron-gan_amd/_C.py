@@ -43,6 +43,7 @@ SIGNATURES = {
     "ngan_final_dot_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "ngan_final_dot_dx": [_P, _P, _P, _I, _I, _I, _F, _P],
     "ngan_final_dot_dw": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "ngan_conv3x3_pack_many": [_P, _I, _L, _P],
     "ngan_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
 }
 NON_STATUS = {
@@ -52,6 +53,7 @@ NON_STATUS = {
     "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
     "ngan_conv3x3_uses_bf16x3": ([_I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_packed_floats": ([_I, _I, _I], _L),
+    "ngan_conv3x3_pack_elements": ([_I, _I, _I, _I], _L),
 }
 
 _lib = None

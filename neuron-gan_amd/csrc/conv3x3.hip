@@ -999,6 +999,66 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision,
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// One launch that (re)packs many weights: entry e = {src, dst, Cout, Cin, mode, precision, scale, first output index}.
+// Used after every optimiser step instead of one small launch per (weight, mode, precision).
+// ---------------------------------------------------------------------------------------------------------
+struct PackEntry { const float* src; float* dst; int cout, cin, mode, precision; float scale; int pad; long first; };
+
+__global__ __launch_bounds__(256) void pack_many_kernel(const PackEntry* __restrict__ table, int n_entries, long total) {
+    const long gidx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gidx >= total) return;
+    int lo = 0, hi = n_entries - 1;                       // last entry with first <= gidx
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first <= gidx) lo = mid; else hi = mid - 1;
+    }
+    const PackEntry e = table[lo];
+    const long idx = gidx - e.first;
+    const int Cout = e.cout, Cin = e.cin, mode = e.mode;
+    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    if (e.precision == 0) {
+        const int G = K / 16, MT = N / 16;
+        const int i = idx & 3, lane = (idx >> 2) & 63;
+        long r = idx >> 8;
+        const int mt = r % MT; r /= MT;
+        const int g = r % G;
+        const int tap = r / G;
+        const int n = mt * 16 + (lane & 15), k = g * 16 + 4 * (lane >> 4) + i;
+        const float v = mode == 0 ? e.src[((long)n * Cin + k) * 9 + tap] : e.src[((long)k * Cin + n) * 9 + (8 - tap)];
+        e.dst[idx] = v * e.scale;
+    } else {
+        const int MT = N / 16;
+        const int j = idx & 7, lane = (idx >> 3) & 63, part = (idx >> 9) & 1;
+        long r = idx >> 10;
+        const int mt = r % MT;
+        const int step = r / MT;
+        const int n = mt * 16 + (lane & 15), kk = 8 * (lane >> 4) + j;
+        const int tap = K == 16 ? 2 * step + (kk >> 4) : step;
+        const int k = K == 16 ? (kk & 15) : kk;
+        float v = 0.f;
+        if (tap < 9) v = mode == 0 ? e.src[((long)n * Cin + k) * 9 + tap] : e.src[((long)k * Cin + n) * 9 + (8 - tap)];
+        v *= e.scale;
+        const __bf16 hi16 = (__bf16)v;
+        reinterpret_cast<__bf16*>(e.dst)[idx] = part == 0 ? hi16 : (__bf16)(v - (float)hi16);
+    }
+}
+
+extern "C" long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int precision) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
+    if (precision == 0) return 9L * Cin * Cout;
+    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    if (K > 32 || N > 32) return 0;
+    return (long)(K == 16 ? 5 : 9) * (N / 16) * 2 * 64 * 8;
+}
+
+extern "C" int ngan_conv3x3_pack_many(const void* table, int n_entries, long total_elements, void* stream) {
+    NGAN_REQUIRE(table && n_entries > 0 && total_elements > 0, NGAN_ERR_ARG, "conv3x3_pack_many: bad argument");
+    hipLaunchKernelGGL(pack_many_kernel, dim3(ngan::ceil_div(total_elements, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PackEntry*>(table), n_entries, total_elements);
+    return ngan::launch_status("ngan_conv3x3_pack_many");
+}
+
 extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
     if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
     if (precision == 0) return 9L * Cin * Cout;

@@ -41,35 +41,87 @@ def get_conv_precision():
 PIXELNORM_EPS = 1e-8  # models.py:105 of the reference
 
 # ---------------------------------------------------------------------------------------------------------
-# packed-weight cache.  Packed (MFMA fragment order, pre-scaled) copies are valid for one "weight epoch":
-# the optimiser updates parameters through raw pointers, so it must call bump_weight_epoch() afterwards.
+# packed weights.  A conv weight is used in MFMA-fragment order, pre-scaled, possibly split into bf16 hi/lo, and in a
+# forward and a flipped (dgrad) orientation.  Packed copies of PARAMETERS are persistent: one buffer per
+# (parameter, orientation, precision, scale), registered on first use; after an optimiser step (which updates the
+# parameters through raw pointers) `bump_weight_epoch()` marks them stale and `refresh_packed()` re-packs all of them
+# with one table-driven launch.  Packed copies of other tensors (the "weights" of a double-backward) are one-shot.
 # ---------------------------------------------------------------------------------------------------------
+import struct
+
+import numpy as np
+
 _weight_epoch = 0
-_pack_cache = {}
+_registry = {}          # key -> dict(ref, packed, cout, cin, mode, prec, scale, epoch)
+_table = None           # (device table tensor, n_entries, total_elements, registry size it was built for)
 
 
 def bump_weight_epoch():
+    """Every packed copy is stale from now on (call after changing parameters through raw pointers)."""
     global _weight_epoch
     _weight_epoch += 1
-    _pack_cache.clear()
+
+
+def clear_packed():
+    """Forget every packed buffer (used around HIP-graph capture so that no buffer of a private pool is kept)."""
+    global _table
+    _registry.clear()
+    _table = None
+    bump_weight_epoch()
+
+
+def refresh_packed():
+    """Re-pack every registered parameter with ONE launch; returns the number of entries refreshed."""
+    global _table
+    live = [e for e in _registry.values() if e["ref"]() is not None]
+    if not live:
+        return 0
+    if _table is None or _table[3] != len(live):
+        rec, first = b"", 0
+        for e in live:
+            w = e["ref"]()
+            rec += struct.pack("<QQiiiifiq", w.data_ptr(), e["packed"].data_ptr(), e["cout"], e["cin"], e["mode"], e["prec"],
+                               e["scale"], 0, first)
+            first += _C.lib().ngan_conv3x3_pack_elements(e["cout"], e["cin"], e["mode"], e["prec"])
+        dev = live[0]["packed"].device
+        table = torch.from_numpy(np.frombuffer(rec, dtype=np.uint8).copy()).to(dev)
+        _table = (table, len(live), first, len(live), [e["ref"]().data_ptr() for e in live])
+    elif _table[4] != [e["ref"]().data_ptr() for e in live]:
+        _table = None                      # a parameter was re-homed: rebuild
+        return refresh_packed()
+    _C.call("ngan_conv3x3_pack_many", _table[0], _table[1], _table[2])
+    for e in live:
+        e["epoch"] = _weight_epoch
+        e["version"] = e["ref"]()._version
+    return len(live)
 
 
 def _packed(weight, mode, scale, precision=0):
-    # identity is checked through a weak reference: a data_ptr alone can be recycled by the allocator
-    key = (id(weight), weight.data_ptr(), weight._version, mode, float(scale), precision, _weight_epoch)
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is weight:
-        return hit[1]
     cout, cin = weight.shape[0], weight.shape[1]
-    w = weight.detach()
-    if not w.is_contiguous():
-        w = w.contiguous()
     n_packed = _C.conv3x3_packed_floats(cout, cin, precision)
     if n_packed <= 0:
         raise RuntimeError(f"conv3x3: unsupported channel counts Cin={cin}, Cout={cout} (must be positive multiples of 16)")
-    packed = torch.empty(n_packed, device=weight.device, dtype=torch.float32)
+    persistent = isinstance(weight, torch.nn.Parameter) and weight.is_contiguous() and not torch.cuda.is_current_stream_capturing()
+    key = (id(weight), mode, precision, float(scale))
+    e = _registry.get(key)
+    if e is not None and e["ref"]() is weight and e["data_ptr"] == weight.data_ptr():
+        if e["epoch"] == _weight_epoch and e["version"] == weight._version:
+            return e["packed"]
+        packed = e["packed"]               # stale: re-pack in place (refresh_packed() normally did this already)
+    else:
+        e = None
+        packed = torch.empty(n_packed, device=weight.device, dtype=torch.float32)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
     _C.call("ngan_conv3x3_pack_weights", w, packed, cout, cin, mode, float(scale), precision)
-    _pack_cache[key] = (weakref.ref(weight), packed)
+    if e is not None:
+        e["epoch"], e["version"] = _weight_epoch, weight._version
+    elif persistent:
+        global _table
+        _registry[key] = dict(ref=weakref.ref(weight), packed=packed, cout=cout, cin=cin, mode=mode, prec=precision,
+                              scale=float(scale), epoch=_weight_epoch, version=weight._version, data_ptr=weight.data_ptr())
+        _table = None
     return packed
 
 

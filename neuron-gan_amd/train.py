@@ -110,7 +110,8 @@ class FusedAdam:
             self._push()
         _C.call("ngan_adam_step", f.flat, f.grad, f.exp_avg, f.exp_avg_sq, f.seg_off, f.seg_len, f.seg_active, f.seg_step,
                 len(f.params), f.chunk_seg, f.chunk_off, int(f.chunk_seg.numel()), self.hyper)
-        ops.bump_weight_epoch()  # packed conv weights are stale now
+        ops.bump_weight_epoch()  # packed conv weights are stale now ...
+        ops.refresh_packed()     # ... re-pack every registered one with a single launch
 
 
 def exchange_gradients(flat: FlatParams, world: int, group=None, force: bool = False):
@@ -312,7 +313,8 @@ class PGGANTrainer:
                 self.train_iteration(self._static_real)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ops.bump_weight_epoch()
+        ops.bump_weight_epoch()   # the warm-up registered every packed weight (persistent buffers, allocated outside capture)
+        ops.refresh_packed()
         if not segmented:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -331,7 +333,6 @@ class PGGANTrainer:
                 self.opt_g.step()
             self._static_stats = stats
             self._graph = [ga, gb, gc]
-        ops.bump_weight_epoch()  # drop packed-weight buffers that live in the graphs' private pool
         return self._graph
 
     def replay(self, real=None):
