@@ -84,6 +84,15 @@ int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspa
                        int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate, int precision,
                        void* stream);
 
+/* Deferred reduction.  ngan_conv3x3_wgrad(..., accumulate = 2, ...) writes the slabs only; later ONE call reduces the slabs of many
+ * such calls (a whole backward pass) and merges up to 4 contributions to the same gradient tensor in a fixed order.
+ * `entries`: host array of n records
+ *   { const float* partial[4]; float* gw; int nparts[4]; int nsrc, nslices, n_ci_slices, co_s, ci_s, K, accumulate, reserved;
+ *     float scale[4]; }                                                                                     (104 bytes)
+ * with (nparts, nslices, n_ci_slices, co_s, ci_s) from ngan_conv3x3_wgrad_plan (out5).  accumulate != 0: gw += sum. */
+int ngan_conv3x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int* out5);
+int ngan_conv3x3_wgrad_reduce_many(const void* entries, int n, void* stream);
+
 /* ---- LeakyReLU -> PixelNorm: models.py:263-264, 118-126 (ATen leaky_relu, pow, mean, sqrt, div) ---------------
  * fwd:    a = lrelu(c + bias); r = sqrt(mean_c(a^2) + eps); y = a / r
  * bwd:    gc = m * ((gy - y*mean_c(gy*y)) / r + gr*y/C),  m = (y > 0 ? 1 : slope); gr (npix) may be NULL

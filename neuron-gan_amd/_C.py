@@ -44,6 +44,7 @@ SIGNATURES = {
     "ngan_final_dot_dx": [_P, _P, _P, _I, _I, _I, _F, _P],
     "ngan_final_dot_dw": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "ngan_conv3x3_pack_many": [_P, _I, _L, _P],
+    "ngan_conv3x3_wgrad_reduce_many": [_P, _I, _P],
     "ngan_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
 }
 NON_STATUS = {
@@ -54,6 +55,7 @@ NON_STATUS = {
     "ngan_conv3x3_uses_bf16x3": ([_I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_packed_floats": ([_I, _I, _I], _L),
     "ngan_conv3x3_pack_elements": ([_I, _I, _I, _I], _L),
+    "ngan_conv3x3_wgrad_plan": ([_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int)], _I),
 }
 
 _lib = None
@@ -147,3 +149,19 @@ def conv3x3_uses_bf16x3(B, H, W, K, N, resample, precision) -> int:
 
 def conv3x3_packed_floats(cout, cin, precision) -> int:
     return int(lib().ngan_conv3x3_packed_floats(cout, cin, precision))
+
+
+def wgrad_plan(B, H, W, Cin, Cout):
+    out = (ctypes.c_int * 5)()
+    if lib().ngan_conv3x3_wgrad_plan(B, H, W, Cin, Cout, out) != 0:
+        raise RuntimeError(lib().ngan_last_error().decode())
+    return tuple(out)
+
+
+def wgrad_reduce_many(raw_entries: bytes, n: int):
+    """raw_entries: n packed 104-byte records (see include/ngan.h)"""
+    buf = ctypes.create_string_buffer(raw_entries, len(raw_entries))
+    stream = torch.cuda.current_stream().cuda_stream
+    status = lib().ngan_conv3x3_wgrad_reduce_many(ctypes.cast(buf, ctypes.c_void_p), n, stream)
+    if status != 0:
+        raise RuntimeError(f"ngan_conv3x3_wgrad_reduce_many failed with status {status}: {lib().ngan_last_error().decode()}")

@@ -1143,15 +1143,98 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     return NGAN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Deferred slab reduction: one launch reduces the slabs of MANY weight-gradient calls (all of a backward pass).
+// An entry describes one gradient tensor and up to 4 slab sets that contribute to it (e.g. the real+fake pass and the
+// two gradient-penalty terms of a critic weight), summed in a fixed order: bit-reproducible.  Entries travel as kernel
+// arguments (no device table), so the launch can be captured into a HIP graph.
+// ---------------------------------------------------------------------------------------------------------
+struct ReduceEntry {
+    const float* partial[4]; float* gw;
+    int nparts[4];
+    int nsrc, nslices, n_ci_slices, co_s, ci_s, K, accumulate, first_block;
+    float scale[4];
+};
+constexpr int kReduceBatch = 24;
+struct ReduceBatch { ReduceEntry e[kReduceBatch]; int n; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(ReduceBatch b) {
+    __shared__ float red[256];
+    int ei = 0;
+    for (int i = 1; i < b.n; ++i)
+        if ((int)blockIdx.x >= b.e[i].first_block) ei = i;
+    const ReduceEntry& e = b.e[ei];
+    const int slab = 9 * e.co_s * e.ci_s;
+    const long M = (long)e.nslices * slab;
+    const int tid = threadIdx.x;
+    const long i = (long)(blockIdx.x - e.first_block) * 16 + (tid & 15);
+    float total = 0.f;
+    for (int s = 0; s < e.nsrc; ++s) {
+        float acc = 0.f;
+        if (i < M)
+            for (int j = tid >> 4; j < e.nparts[s]; j += 16) acc += e.partial[s][(long)j * M + i];
+        __syncthreads();
+        red[tid] = acc;
+        __syncthreads();
+        if (tid < 16) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += red[tid + 16 * j];
+            total = fmaf(t, e.scale[s], total);
+        }
+    }
+    if (tid < 16 && i < M) {
+        int r = (int)(i % slab);
+        const int slice = (int)(i / slab);
+        const int ci_l = r % e.ci_s; r /= e.ci_s;
+        const int co_l = r % e.co_s;
+        const int tap = r / e.co_s;
+        const int co = (slice / e.n_ci_slices) * e.co_s + co_l, ci = (slice % e.n_ci_slices) * e.ci_s + ci_l;
+        float* o = e.gw + ((long)co * e.K + ci) * 9 + tap;
+        *o = e.accumulate ? *o + total : total;
+    }
+}
+
 extern "C" size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % 16) return 0;
     WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
     return (size_t)p.nwx * p.nslices * 9 * p.co_s * p.ci_s * sizeof(float);
 }
 
+extern "C" int ngan_conv3x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int* out5) {
+    NGAN_REQUIRE(out5 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_ARG,
+                 "conv3x3_wgrad_plan: bad argument");
+    WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
+    out5[0] = p.nwx; out5[1] = p.nslices; out5[2] = p.n_ci_slices; out5[3] = p.co_s; out5[4] = p.ci_s;
+    return NGAN_OK;
+}
+
+// entries: host array of n records { const float* partial[4]; float* gw; int nparts[4]; int nsrc, nslices, n_ci_slices, co_s,
+// ci_s, K, accumulate, first_block(ignored); float scale[4]; }  (104 bytes each)
+extern "C" int ngan_conv3x3_wgrad_reduce_many(const void* entries, int n, void* stream) {
+    NGAN_REQUIRE(entries && n > 0, NGAN_ERR_ARG, "conv3x3_wgrad_reduce_many: bad argument");
+    const ReduceEntry* src = reinterpret_cast<const ReduceEntry*>(entries);
+    for (int base = 0; base < n; base += kReduceBatch) {
+        ReduceBatch b;
+        b.n = n - base < kReduceBatch ? n - base : kReduceBatch;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.e[i] = src[base + i];
+            NGAN_REQUIRE(b.e[i].nsrc >= 1 && b.e[i].nsrc <= 4 && b.e[i].gw, NGAN_ERR_ARG, "conv3x3_wgrad_reduce_many: bad entry %d", base + i);
+            b.e[i].first_block = blocks;
+            blocks += ngan::ceil_div((long)b.e[i].nslices * 9 * b.e[i].co_s * b.e[i].ci_s, 16);
+        }
+        hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+        int st = ngan::launch_status("ngan_conv3x3_wgrad_reduce_many");
+        if (st) return st;
+    }
+    return NGAN_OK;
+}
+
 extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
                                   int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate,
                                   int precision, void* stream) {
+    // accumulate == 2: write the slabs only; the caller reduces them later with ngan_conv3x3_wgrad_reduce_many
     NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "conv3x3_wgrad: null pointer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_wgrad: bad dims B=%d H=%d W=%d", B, H, W);
     NGAN_REQUIRE(Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
@@ -1168,7 +1251,7 @@ extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, flo
     else if (p.co_s == 32) st = launch_wgrad<2, 1>(a, p, resample, precision, s);
     else if (p.ci_s == 32) st = launch_wgrad<1, 2>(a, p, resample, precision, s);
     else st = launch_wgrad<1, 1>(a, p, resample, precision, s);
-    if (st) return st;
+    if (st || accumulate == 2) return st;
     const long M = (long)p.nslices * 9 * p.co_s * p.ci_s;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ngan::ceil_div(M, 16)), dim3(256), 0, s, workspace, gw, p.nwx,
                        p.nslices, p.n_ci_slices, p.co_s, p.ci_s, Cin, scale, accumulate);

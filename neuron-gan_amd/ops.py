@@ -187,11 +187,57 @@ def _run_dgrad(g, weight, resample, scale):
     return gfull
 
 
+# ---- deferred slab reduction: inside `deferred_wgrad()` the in-place weight gradients only write their slabs; leaving the
+# block reduces all of them with one launch (contributions to the same gradient merged, fixed order)
+_defer_depth = 0
+_pending = {}       # gradient data_ptr -> dict(gw, plan, cin, sources=[(workspace, nparts, scale)])
+
+
+class deferred_wgrad:
+    def __enter__(self):
+        global _defer_depth
+        _defer_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _defer_depth
+        _defer_depth -= 1
+        if _defer_depth == 0:
+            flush_wgrad()
+        return False
+
+
+def flush_wgrad():
+    if not _pending:
+        return 0
+    rec, n = b"", 0
+    for e in _pending.values():
+        src = e["sources"]
+        for first in range(0, len(src), 4):            # at most 4 slab sets per record; further records accumulate
+            part = src[first:first + 4]
+            ptrs = [s[0].data_ptr() for s in part] + [0] * (4 - len(part))
+            nparts = [s[1] for s in part] + [0] * (4 - len(part))
+            scales = [s[2] for s in part] + [0.0] * (4 - len(part))
+            _, nslices, n_ci, co_s, ci_s = e["plan"]
+            rec += struct.pack("<4QQ4i8i4f", *ptrs, e["gw"].data_ptr(), *nparts, len(part), nslices, n_ci, co_s, ci_s, e["cin"], 1, 0,
+                               *scales)
+            n += 1
+    _C.wgrad_reduce_many(rec, n)
+    _pending.clear()
+    return n
+
+
 def _run_wgrad(x, g, resample, scale, accumulate_into=None):
     b, h, w, cout = g.shape
     cin = x.shape[3]
     gw = accumulate_into if accumulate_into is not None else torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
     ws = torch.empty(_C.wgrad_workspace_bytes(b, h, w, cin, cout) // 4, device=g.device, dtype=torch.float32)
+    if accumulate_into is not None and _defer_depth > 0:
+        _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 2, _conv_precision)
+        plan = _C.wgrad_plan(b, h, w, cin, cout)
+        e = _pending.setdefault(gw.data_ptr(), dict(gw=gw, plan=plan, cin=cin, sources=[]))
+        e["sources"].append((ws, plan[0], float(scale)))
+        return gw
     _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 1 if accumulate_into is not None else 0,
             _conv_precision)
     return gw

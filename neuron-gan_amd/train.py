@@ -231,7 +231,8 @@ class PGGANTrainer:
         loss, s_real, s_fake = self.d_loss(real, fake_images=fakes[:b])  # train.py:358
         gp = self.gp_loss(real, x_tilde=fakes[b:], epsilon=eps)  # train.py:361
         loss = loss + gp  # train.py:362
-        loss.backward()  # train.py:365
+        with ops.deferred_wgrad():   # weight-gradient slabs of the whole pass are reduced by one launch at the end
+            loss.backward()  # train.py:365
         return {"D_loss": loss.detach(), "score_real": s_real.detach(), "score_fake": s_fake.detach(), "D_grad_pen": gp.detach()}
 
     def d_step(self, real, z_d=None, z_gp=None, eps=None):
@@ -249,7 +250,8 @@ class PGGANTrainer:
             p.requires_grad_(False)
         try:
             loss, _ = self.g_loss(real, z=self._latent(b, z))  # train.py:376
-            loss.backward()  # train.py:384
+            with ops.deferred_wgrad():
+                loss.backward()  # train.py:384
         finally:
             for p in d_params:
                 p.requires_grad_(True)
