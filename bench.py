@@ -215,15 +215,25 @@ def main():
             summ = probe.summary()
             dom = max(summ, key=lambda k: summ[k]["seconds"])
             d = summ[dom]
+            # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3
+            # passes over this same command; committed summary, see profiles/README.md).  null if no summary for this mode.
+            traffic, traffic_src = None, None
+            tfile = os.path.join(ROOT, "profiles", f"r01_traffic_{args.precision}.json")
+            if os.path.exists(tfile) and args.res == 512 and args.batch == 16:
+                with open(tfile) as fh:
+                    tk = json.load(fh)["kernels"].get(dom)
+                if tk:
+                    traffic, traffic_src = tk["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
             if dom.rstrip(">").endswith(", 1"):   # split-bf16 instance: ~5x the fp32 MFMA rate, so HBM is the binding roof
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": None, "launches": d["launches"],
+                                   "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                                   "algorithmic_bytes_per_launch": d["gbs"] * 1e9 * d["avg_us"] * 1e-6, "launches": d["launches"],
                                    "avg_launch_us": d["avg_us"], "timing": probe_note,
                                    "fp32_equivalent_tflops": d["tflops"]}
             else:
                 out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                                   "launches": d["launches"], "avg_launch_us": d["avg_us"], "timing": probe_note}
+                                   "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                                   "traffic_source": traffic_src, "launches": d["launches"], "avg_launch_us": d["avg_us"], "timing": probe_note}
             tot_f = sum(v["flops"] for v in summ.values())
             tot_s = sum(v["seconds"] for v in summ.values())
             out["conv_family"] = {"tflops": tot_f / tot_s / 1e12, "seconds_per_step": tot_s / args.steps,
