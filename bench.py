@@ -142,6 +142,8 @@ def main():
     trainer = pkg.train.PGGANTrainer(G, D, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001,
                                      device_latents=True)
     trainer.force_exchange = args.force_dist
+    if args.force_dist:
+        trainer.enable_stem_exchange()
     torch.manual_seed(123 + rank)
     pool = [(torch.rand(args.batch, 1, args.res, args.res) * 2 - 1).to(device) for _ in range(4)]
     torch.cuda.manual_seed(1000 + rank)

@@ -643,6 +643,12 @@ class FadeBwd(Function):
 # ---------------------------------------------------------------------------------------------------------
 # generator stem and critic head
 # ---------------------------------------------------------------------------------------------------------
+# Data-parallel hook for the generator stem: when set, LinearLReLUPN.backward hands (z, gc, weight, scale) to the sink instead
+# of forming the (C*S, K) weight gradient itself -- the step driver all-gathers the rank-B factors and forms the full-batch
+# gradient locally (train.StemGradExchange), which moves ~2 MB per rank instead of all-reducing 67 MB.
+linear_grad_sink = None
+
+
 class LinearLReLUPN(Function):
     """y (B,S,S,C) = PixelNorm(LeakyReLU(Unflatten(Linear(scale*z, W)))): generator stem, first order."""
 
@@ -671,8 +677,11 @@ class LinearLReLUPN(Function):
         _C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, b * s2, c, float(slope))
         gz = gw = None
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(weight)
-            _C.call("ngan_linear_wgrad", z, gc, gw, b, k, s2, c, float(scale))
+            if linear_grad_sink is not None:
+                linear_grad_sink(z, gc, weight, s2, c, scale)      # gradient is formed later from the gathered factors
+            else:
+                gw = torch.empty_like(weight)
+                _C.call("ngan_linear_wgrad", z, gc, gw, b, k, s2, c, float(scale))
         if ctx.needs_input_grad[0]:
             gz = torch.empty_like(z)
             _C.call("ngan_linear_dgrad", gc, weight.detach(), gz, b, k, s2, c, float(scale))

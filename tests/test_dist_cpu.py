@@ -73,6 +73,20 @@ def _worker(rank, world, port, fixture):
                 # (the last bias' gradient is a cancellation of -1 + 1: compare against the overall gradient scale too)
                 err = float((got - full[name]).abs().max() / (full[name].abs().max() + 1e-2 * gmax))
                 assert err < 1e-5, (name, err)
+        # 3. generator stem: gathered rank-B factors give the same gradient as all-reducing the per-rank products
+        torch.manual_seed(100 + rank)
+        b, k, s2, c, scale = 3, 8, 4, 5, 0.25
+        z, gc = torch.randn(b, k), torch.randn(b, 2, 2, c)
+        w = torch.nn.Parameter(torch.zeros(c * s2, k))
+        w.grad = torch.zeros_like(w)
+        ref_fn = lambda zs, gs, out, n, kk, ss, cc, sc: out.copy_(sc * torch.einsum("bpc,bk->cpk", gs.reshape(n, ss, cc), zs).reshape(cc * ss, kk))
+        ex = pkg.train.StemGradExchange(w, world, wgrad_fn=ref_fn)
+        ex.sink(z, gc, w, s2, c, scale)
+        ex.finish()
+        mine = torch.zeros_like(w)
+        ref_fn(z, gc, mine, b, k, s2, c, scale)
+        dist.all_reduce(mine)
+        assert torch.allclose(w.grad, mine, atol=1e-5)
         # inactive tensors stay exactly zero on every rank
         for a, p in zip(flat.active_host, flat.params):
             if not a:

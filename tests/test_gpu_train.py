@@ -108,3 +108,27 @@ def test_epoch_driver_grows_checkpoints_and_resumes(ngan, tmp_path):
     assert len(more["G_loss"]) == 1 and np.isfinite(more["G_loss"][0])
     grid = utils.plot_gen_samples(G2, N_images=4, seed=0)
     assert grid.shape[0] == 1 and grid.shape[1] > 2 * 16
+
+
+def test_stem_factor_exchange_matches_plain_gradient(ngan):
+    """The data-parallel path forms the stem's weight gradient from (gathered) factors after the backward pass; with one rank
+    that must give exactly the weights of the plain path."""
+    fix = load_golden("small_res8_warm")
+    res, alpha, init, latent, batch, _ = fix["meta"]
+    out = []
+    for use_stem in (False, True):
+        G = ngan.models.Generator_PG([32, 16, 16], image_size_init=int(init), latent_dim=int(latent))
+        D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=int(init))
+        G.set_resolution(int(res), float(alpha))
+        D.set_resolution(int(res), float(alpha))
+        G.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "G/").items()})
+        D.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "D/").items()})
+        tr = ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), learning_rate=1e-3)
+        if use_stem:
+            tr.enable_stem_exchange()
+            assert tr.stem is not None
+        t = lambda k: torch.from_numpy(fix[k]).to(DEV)
+        tr.train_iteration(t("real"), z_d=t("z_d"), z_gp=t("z_gp"), eps=t("eps"), z_g=t("z_g"))
+        out.append({k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
