@@ -10,42 +10,9 @@
 // channels with two shuffles and stores 16 B per lane, fully coalesced.
 // The avg-pool / bilinear-x2 resampling in front of a block's first conv (models.py:254, 257) is applied
 // while the halo tile is staged, so the resampled tensor never exists in HBM.
-#include "ngan_common.h"
+#include "conv3x3_shared.h"
 
 namespace {
-
-
-struct ConvArgs {
-    const float* x; const float* wp; const float* bias; float* y; float* rn;
-    int B, H, W, K, N, tiles_x, tiles_y;
-    float slope, eps;
-};
-
-// 4 consecutive channels (starting at ch) of conv-input pixel (gy, gx) of image b, after resampling.
-// C = channel count of x.  Out-of-image pixels are the conv's zero padding.
-template <int RES>
-__device__ __forceinline__ float4 load_resampled(const float* __restrict__ x, int b, int gy, int gx, int ch,
-                                                 int H, int W, int C) {
-    if (gy < 0 || gy >= H || gx < 0 || gx >= W) return f4zero();
-    if (RES == NGAN_RESAMPLE_NONE) {
-        return ld4(x + (((long)b * H + gy) * W + gx) * C + ch);
-    } else if (RES == NGAN_RESAMPLE_POOL2) {
-        const long W2 = 2L * W;
-        const float* p = x + (((long)b * 2 * H + 2 * gy) * W2 + 2 * gx) * C + ch;
-        float4 v = f4add(f4add(ld4(p), ld4(p + C)), f4add(ld4(p + W2 * C), ld4(p + W2 * C + C)));
-        return f4scale(v, 0.25f);
-    } else {
-        const int h = H >> 1, w = W >> 1;
-        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
-        up2_taps(gy, h, y0, y1, wy0, wy1);
-        up2_taps(gx, w, x0, x1, wx0, wx1);
-        const float* r0 = x + ((long)b * h + y0) * w * C + ch;
-        const float* r1 = x + ((long)b * h + y1) * w * C + ch;
-        float4 top = f4fma(ld4(r0 + (long)x1 * C), wx1, f4scale(ld4(r0 + (long)x0 * C), wx0));
-        float4 bot = f4fma(ld4(r1 + (long)x1 * C), wx1, f4scale(ld4(r1 + (long)x0 * C), wx0));
-        return f4fma(bot, wy1, f4scale(top, wy0));
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // weight packing: OIHW -> [tap][k-group g][n-tile mt][lane][4], value * scale.
@@ -73,13 +40,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // Split-bf16 ("bf16x3") packing for v_mfma_f32_16x16x32_bf16: every weight w*scale is written as hi = bf16(w) and
 // lo = bf16(w - hi).  Layout [step][n-tile mt][part hi/lo][lane][8]; lane l holds n = 16*mt + (l & 15) and
 // k = 8*(l >> 4) + j.  K = 16: a step is a PAIR of taps (k < 16 -> tap 2*step, k >= 16 -> tap 2*step + 1; the 10th
-// tap is zero padding), 5 steps.  K = 32: a step is one tap, k = input channel, 9 steps.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
+// tap is zero padding), 5 steps.  K = 32*KG: step = kg*9 + tap covers input channels 32*kg .. 32*kg + 31 of one tap,
+// 9*KG steps (K = 32: a step is one tap; K = 64, 128: conv3x3_mid.hip).
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ packed, int Cout, int Cin,
                                            int mode, float scale) {
     const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
-    const int MT = N / 16, nstep = K == 16 ? 5 : 9;
+    const int MT = N / 16, nstep = K == 16 ? 5 : 9 * (K / 32);
     const long total = (long)nstep * MT * 2 * 64 * 8;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -88,8 +54,8 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, __bf16* 
     const int mt = r % MT;
     const int step = r / MT;
     const int n = mt * 16 + (lane & 15), kk = 8 * (lane >> 4) + j;
-    const int tap = K == 16 ? 2 * step + (kk >> 4) : step;
-    const int k = K == 16 ? (kk & 15) : kk;
+    const int tap = K == 16 ? 2 * step + (kk >> 4) : step % 9;
+    const int k = K == 16 ? (kk & 15) : (step / 9) * 32 + kk;
     float v = 0.f;
     if (tap < 9) {
         if (mode == 0) v = w[((long)n * Cin + k) * 9 + tap];
@@ -799,8 +765,6 @@ __global__ __launch_bounds__(256, (COT * CIT == 1) ? 4 : 2) void wgrad_kernel(Wg
 // same permutation on both operands), so each 32-lane half of a read touches 256 contiguous bytes: conflict-free,
 // and the dx tap shift is just a different row address (no alignment constraint).
 // ---------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base_lo16, const __bf16* base_hi16) {
     const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)base_lo16);
     const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)base_hi16);
@@ -1034,8 +998,8 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackEntry* __restr
         const int mt = r % MT;
         const int step = r / MT;
         const int n = mt * 16 + (lane & 15), kk = 8 * (lane >> 4) + j;
-        const int tap = K == 16 ? 2 * step + (kk >> 4) : step;
-        const int k = K == 16 ? (kk & 15) : kk;
+        const int tap = K == 16 ? 2 * step + (kk >> 4) : step % 9;
+        const int k = K == 16 ? (kk & 15) : (step / 9) * 32 + kk;
         float v = 0.f;
         if (tap < 9) v = mode == 0 ? e.src[((long)n * Cin + k) * 9 + tap] : e.src[((long)k * Cin + n) * 9 + (8 - tap)];
         v *= e.scale;
@@ -1044,12 +1008,16 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackEntry* __restr
     }
 }
 
+// bf16 elements of a split-bf16 packed weight for contraction K, outputs N (0: no split-bf16 kernel takes this shape)
+static long bf16x3_elements(int K, int N) {
+    if (K <= 0 || N <= 0 || N % 16 || (K != 16 && K % 32)) return 0;
+    return (long)(K == 16 ? 5 : 9 * (K / 32)) * (N / 16) * 2 * 64 * 8;
+}
+
 extern "C" long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int precision) {
     if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
     if (precision == 0) return 9L * Cin * Cout;
-    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
-    if (K > 32 || N > 32) return 0;
-    return (long)(K == 16 ? 5 : 9) * (N / 16) * 2 * 64 * 8;
+    return mode == 0 ? bf16x3_elements(Cin, Cout) : bf16x3_elements(Cout, Cin);
 }
 
 extern "C" int ngan_conv3x3_pack_many(const void* table, int n_entries, long total_elements, void* stream) {
@@ -1062,14 +1030,14 @@ extern "C" int ngan_conv3x3_pack_many(const void* table, int n_entries, long tot
 extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
     if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
     if (precision == 0) return 9L * Cin * Cout;
-    if (Cout > 32 || Cin > 32) return 0;
-    return 10L * Cout * 32;   // per (k, n) orientation at most 9 steps x 2 parts x 512 bf16 per n-tile; 10*Cout*32 floats covers both
+    const long e0 = bf16x3_elements(Cin, Cout), e1 = bf16x3_elements(Cout, Cin);   // forward / flipped orientation
+    return ((e0 > e1 ? e0 : e1) + 1) / 2;
 }
 
 extern "C" int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision) {
     if (precision != 1 || B <= 0 || H <= 0 || W <= 0) return 0;
-    if (!(N == 16 || N == 32) || !(K == 16 || K == 32)) return 0;
-    return persist_eligible(B, H, W, K, N, resample) ? 1 : 0;
+    if (persist_eligible(B, H, W, K, N, resample)) return 1;
+    return ngan::conv3x3_mid_eligible(B, H, W, K, N) ? 1 : 0;
 }
 
 extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int Cin, int mode, float scale,
@@ -1080,9 +1048,9 @@ extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int
     NGAN_REQUIRE(mode == 0 || mode == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: mode %d", mode);
     NGAN_REQUIRE(precision == 0 || precision == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
     if (precision == 1) {
-        NGAN_REQUIRE(Cout <= 32 && Cin <= 32, NGAN_ERR_SHAPE, "conv3x3_pack_weights: split-bf16 packing needs Cin, Cout <= 32");
         const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
-        const long tot = (long)(K == 16 ? 5 : 9) * (N / 16) * 2 * 64 * 8;
+        const long tot = bf16x3_elements(K, N);
+        NGAN_REQUIRE(tot > 0, NGAN_ERR_SHAPE, "conv3x3_pack_weights: split-bf16 packing needs K = 16 or a multiple of 32 (K=%d, N=%d)", K, N);
         hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(ngan::ceil_div(tot, 256)), dim3(256), 0, (hipStream_t)stream,
                            w_oihw, reinterpret_cast<__bf16*>(packed), Cout, Cin, mode, scale);
         return ngan::launch_status("ngan_conv3x3_pack_weights(bf16x3)");
@@ -1118,6 +1086,8 @@ extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float
         return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, precision, s)
                        : dispatch_persist<2, 2>(a, resample, epilogue, out_mode, precision, s);
     }
+    if (precision == 1)   // many channels, small image: split-bf16 kernel of conv3x3_mid.hip
+        return ngan::conv3x3_mid_launch(x, packed, bias, y, rnorm, B, H, W, K, N, resample, epilogue, out_mode, slope, eps, s);
     switch (N / 16) {
         case 1: return dispatch_conv<0>(a, resample, epilogue, out_mode, s);
         case 2: return dispatch_conv<1>(a, resample, epilogue, out_mode, s);
@@ -1135,6 +1105,8 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0)
         snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
                  out_mode ? 0 : epilogue, out_mode, precision);
+    else if (precision == 1 && ngan::conv3x3_mid_eligible(B, H, W, K, N))
+        return ngan::conv3x3_mid_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, buf, len);
     else {
         const TileCfg c = kCfg[mti][ci];
         snprintf(buf, len, "conv3x3_kernel<%d, %d, %d, %d, %d, %d, %d>", c.mtw, c.wn, c.pgw, c.pcg, out_mode ? 0 : resample,

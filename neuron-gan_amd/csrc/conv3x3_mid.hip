@@ -1,0 +1,299 @@
+// Split-bf16 ("bf16x3") 3x3 convolution for the many-channel layers on small images (K, N in {32, 64, 96, 128}; the
+// 64/128-channel blocks at 16x16 .. 64x64 of /root/reference/models.py:299-329, 469-503), forward and input-gradient.
+//
+// Why a separate kernel: these layers have only a few thousand pixels, so a launch that fills the chip gives every wave
+// one or two 16x16 MFMA tiles and a K = 9*Cin contraction of up to 1152.  In exact fp32 that chain is MFMA-bound at
+// ~10 us and, worse, exposes one L2 round trip per 16-channel group (measured 21-46 us per launch).  Here
+//   * the whole halo tile (6 x 18 pixels, ALL input channels) is staged into LDS once, already split into bf16 hi/lo;
+//   * a wave streams its weight fragments L2 -> registers through a ring of D+1 register buffers, D steps ahead of the MFMAs
+//     (weights of one layer are <= 590 KB and are shared by every workgroup: they live in L2);
+//   * the 9*K/32 contraction steps are fully unrolled: 3 v_mfma_f32_16x16x32_bf16 per fp32 product group (16 cycles each
+//     instead of 8 x 32 for fp32);
+//   * when the image has too few 4x16-pixel tiles to fill the chip, the OUTPUT CHANNELS are split over workgroups
+//     (blockIdx.y); PixelNorm then needs all channels of a pixel and runs as a second, tiny launch.
+// LDS image: pixel-major, per pixel [32-channel group][hi 32 x bf16 | lo 32 x bf16] + 16 B of padding, which makes the pixel
+// pitch = 4 (mod 64) dwords: the 16 lanes of a ds_read_b128 phase (16 consecutive pixels, same channel octet) hit 16
+// distinct bank quads.
+#include <type_traits>
+#include "conv3x3_shared.h"
+
+namespace {
+
+__device__ __forceinline__ float4 f4select(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// load_resampled (conv3x3_shared.h) without the padding test: (gy, gx) must already be inside the H x W conv input
+template <int RES>
+__device__ __forceinline__ float4 load_inside(const float* __restrict__ x, int b, int gy, int gx, int ch, int H, int W, int C) {
+    if (RES == NGAN_RESAMPLE_NONE) {
+        return ld4(x + (((long)b * H + gy) * W + gx) * C + ch);
+    } else if (RES == NGAN_RESAMPLE_POOL2) {
+        const long W2 = 2L * W;
+        const float* p = x + (((long)b * 2 * H + 2 * gy) * W2 + 2 * gx) * C + ch;
+        return f4scale(f4add(f4add(ld4(p), ld4(p + C)), f4add(ld4(p + W2 * C), ld4(p + W2 * C + C))), 0.25f);
+    } else {
+        const int h = H >> 1, w = W >> 1;
+        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+        up2_taps(gy, h, y0, y1, wy0, wy1);
+        up2_taps(gx, w, x0, x1, wx0, wx1);
+        const float* r0 = x + ((long)b * h + y0) * w * C + ch;
+        const float* r1 = x + ((long)b * h + y1) * w * C + ch;
+        const float4 top = f4fma(ld4(r0 + (long)x1 * C), wx1, f4scale(ld4(r0 + (long)x0 * C), wx0));
+        const float4 bot = f4fma(ld4(r1 + (long)x1 * C), wx1, f4scale(ld4(r1 + (long)x0 * C), wx0));
+        return f4fma(bot, wy1, f4scale(top, wy0));
+    }
+}
+
+template <int KG, int PGW, int MTW, int WN>
+struct MidCfg {
+    static constexpr int WP = 4 / WN;
+    static constexpr int K = KG * 32, NS = 16 * MTW * WN;
+    static constexpr int PITCH = K * 4 + 16;             // bytes per LDS pixel
+    static constexpr int NPIX = 6 * 18;
+    static constexpr int NSTEP = 9 * KG;
+    static constexpr int D = (MTW * PGW >= 8) ? 3 : (MTW * PGW >= 4 ? 5 : 8);   // weight prefetch distance, in steps
+    static_assert(WP * PGW == 4, "a workgroup covers 4 pixel groups (4 rows x 16 pixels)");
+};
+
+template <int KG, int PGW, int MTW, int WN, int EPI, int OUTMODE>
+__global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resample) {
+    using C = MidCfg<KG, PGW, MTW, WN>;
+    constexpr int K = C::K, PITCH = C::PITCH, NPIX = C::NPIX, NSTEP = C::NSTEP, D = C::D;
+    constexpr int SS_BYTES = (EPI == 1 && WN > 1) ? WN * 4 * 16 * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NPIX * PITCH + SS_BYTES];
+    float* ss_l = reinterpret_cast<float*>(smem + NPIX * PITCH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wp = wave / WN;
+    const int p = lane & 15, q = lane >> 4;
+    int t = blockIdx.x;
+    const int txi = t % a.tiles_x; t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int y0 = tyi * 4, x0 = txi * 16;
+    const int MT = a.N >> 4;
+    const int mt0 = blockIdx.y * (C::NS / 16) + wn * MTW;      // this wave's first 16-channel output tile
+
+    // ---- weight stream: fragment (step, mt, part) is 64 lanes x 16 B at bf16x8 index ((step*MT + mt)*2 + part)*64 + lane ----
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(a.wp) + (long)mt0 * 128 + lane;
+    bf16x8 wr[D + 1][MTW][2];
+    auto wload = [&](int slot, int step) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            wr[slot][mt][0] = wfrag[((long)step * MT + mt) * 128];
+            wr[slot][mt][1] = wfrag[((long)step * MT + mt) * 128 + 64];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D && s < NSTEP; ++s) wload(s, s);
+
+    // ---- stage the halo tile, split into bf16 hi / lo.  Branch-free: every load is issued from a clamped (always valid)
+    // address and zeroed afterwards if it is conv padding, so all of a thread's loads are in flight together ----
+    constexpr int CQ = K / 4, NITEM = NPIX * CQ, NST = (NITEM + 255) / 256;
+    float4 stg[NST];
+    auto stage = [&](auto res_tag) {
+        constexpr int RES = decltype(res_tag)::value;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = tid + i * 256;
+            const int pix = e / CQ, c4 = e % CQ;
+            const int ty = pix / 18, tx = pix - ty * 18;
+            const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+            const bool ok = e < NITEM && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+            stg[i] = f4select(ok, load_inside<RES>(a.x, b, cy, cx, c4 * 4, a.H, a.W, K));
+        }
+    };
+    if (resample == NGAN_RESAMPLE_NONE) stage(std::integral_constant<int, NGAN_RESAMPLE_NONE>());
+    else if (resample == NGAN_RESAMPLE_POOL2) stage(std::integral_constant<int, NGAN_RESAMPLE_POOL2>());
+    else stage(std::integral_constant<int, NGAN_RESAMPLE_UP2>());
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = tid + i * 256;
+        if (e < NITEM) {
+            const int pix = e / CQ, c4 = e % CQ;
+            const float4 v = stg[i];
+            bf16x4 hi, lo;
+            hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+            lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+            lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+            unsigned char* dst = smem + pix * PITCH + (c4 >> 3) * 128 + (c4 & 7) * 8;
+            *reinterpret_cast<bf16x4*>(dst) = hi;
+            *reinterpret_cast<bf16x4*>(dst + 64) = lo;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[PGW][MTW];
+#pragma unroll
+    for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this lane's B-operand base: pixel (wp*PGW, p), channel octet q
+    const unsigned char* xb = smem + ((wp * PGW) * 18 + p) * PITCH + q * 16;
+    bf16x8 xh[2][PGW], xl[2][PGW];      // B operands, read from LDS one step ahead of their MFMAs
+    auto xload = [&](int slot, int step) {
+        const int kg = step / 9, tap = step % 9, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg) {
+            const unsigned char* src = xb + ((pg + dy) * 18 + dx) * PITCH + kg * 128;
+            xh[slot][pg] = *reinterpret_cast<const bf16x8*>(src);
+            xl[slot][pg] = *reinterpret_cast<const bf16x8*>(src + 64);
+        }
+    };
+    xload(0, 0);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        if (s + D < NSTEP) wload((s + D) % (D + 1), s + D);
+        if (s + 1 < NSTEP) xload((s + 1) & 1, s + 1);
+        // keep the prefetches HERE: left alone, the machine scheduler sinks every weight load to just above its first use
+        // (shorter live ranges) and the loop then pays one full L2 round trip per fragment (measured: 30 us instead of 8)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const bf16x8 wh = wr[s % (D + 1)][mt][0], wl = wr[s % (D + 1)][mt][1];
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[s & 1][pg], acc[pg][mt], 0, 0, 0);
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[s & 1][pg], acc[pg][mt], 0, 0, 0);
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[s & 1][pg], acc[pg][mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: lane holds channels (mt0 + mt)*16 + 4q + {0..3} of pixel (y0 + wp*PGW + pg, x0 + p) ----
+    float4 bv[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) bv[mt] = a.bias ? ld4(a.bias + (mt0 + mt) * 16 + q * 4) : f4zero();
+    float4 v[PGW][MTW];
+    float ssum[PGW];
+#pragma unroll
+    for (int pg = 0; pg < PGW; ++pg) {
+        float ss = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            float4 c = make_float4(acc[pg][mt][0] + bv[mt].x, acc[pg][mt][1] + bv[mt].y,
+                                   acc[pg][mt][2] + bv[mt].z, acc[pg][mt][3] + bv[mt].w);
+            if (EPI == 1) {
+                c.x = c.x > 0.f ? c.x : a.slope * c.x; c.y = c.y > 0.f ? c.y : a.slope * c.y;
+                c.z = c.z > 0.f ? c.z : a.slope * c.z; c.w = c.w > 0.f ? c.w : a.slope * c.w;
+                ss += f4dot(c, c);
+            }
+            v[pg][mt] = c;
+        }
+        if (EPI == 1) {
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+        }
+        ssum[pg] = ss;
+    }
+    if (EPI == 1 && WN > 1) {
+        if (q == 0) {
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) ss_l[(wn * 4 + wp * PGW + pg) * 16 + p] = ssum[pg];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg) {
+            float ss = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WN; ++w2) ss += ss_l[(w2 * 4 + wp * PGW + pg) * 16 + p];
+            ssum[pg] = ss;
+        }
+    }
+    const float inv_n = 1.0f / (float)a.N;
+#pragma unroll
+    for (int pg = 0; pg < PGW; ++pg) {
+        const int gy = y0 + wp * PGW + pg, gx = x0 + p;
+        const bool valid = gy < a.H && gx < a.W;
+        if (EPI == 1) {
+            const float r = sqrtf(ssum[pg] * inv_n + a.eps);
+            const float inv = 1.0f / r;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) v[pg][mt] = f4scale(v[pg][mt], inv);
+            if (valid && q == 0 && wn == 0) a.rn[((long)b * a.H + gy) * a.W + gx] = r;
+        }
+        if (valid) {
+            const int ch0 = mt0 * 16 + q * 4;
+            if (OUTMODE == 0) {
+                float* o = a.y + (((long)b * a.H + gy) * a.W + gx) * a.N + ch0;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) st4(o + mt * 16, v[pg][mt]);
+            } else {
+                const long W2 = 2L * a.W;
+                float* o = a.y + (((long)b * 2 * a.H + 2 * gy) * W2 + 2 * gx) * a.N + ch0;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const float4 s4 = f4scale(v[pg][mt], 0.25f);
+                    st4(o + mt * 16, s4); st4(o + a.N + mt * 16, s4);
+                    st4(o + W2 * a.N + mt * 16, s4); st4(o + W2 * a.N + a.N + mt * 16, s4);
+                }
+            }
+        }
+    }
+}
+
+// output-channel slice per workgroup: the largest of {N, 64, 32} (a divisor of N) that still gives >= 256 workgroups
+int mid_slice(int n_tiles, int N) {
+    const int cand[3] = {N, 64, 32};
+    for (int i = 0; i < 3; ++i) {
+        const int ns = cand[i];
+        if (ns > N || N % ns || !(ns == 32 || ns == 64 || ns == 128)) continue;
+        if ((long)n_tiles * (N / ns) >= 256) return ns;
+    }
+    return 32;
+}
+
+template <int KG, int PGW, int MTW, int WN>
+int mid_launch_cfg(ConvArgs a, int n_tiles, int n_slices, int resample, int epi, int outmode, hipStream_t s) {
+    const dim3 grid(n_tiles, n_slices), block(256);
+    if (outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 1>), grid, block, 0, s, a, resample);
+    else if (epi) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 1, 0>), grid, block, 0, s, a, resample);
+    else hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 0>), grid, block, 0, s, a, resample);
+    return ngan::launch_status("ngan_conv3x3_fwd(mid)");
+}
+
+template <int KG>
+int mid_launch_kg(const ConvArgs& a, int n_tiles, int ns, int resample, int epi, int outmode, hipStream_t s) {
+    const int n_slices = a.N / ns;
+    if (ns == 32) return mid_launch_cfg<KG, 2, 1, 2>(a, n_tiles, n_slices, resample, epi, outmode, s);
+    if (ns == 64) return mid_launch_cfg<KG, 2, 2, 2>(a, n_tiles, n_slices, resample, epi, outmode, s);
+    return mid_launch_cfg<KG, 4, 2, 4>(a, n_tiles, n_slices, resample, epi, outmode, s);
+}
+
+}  // namespace
+
+namespace ngan {
+
+bool conv3x3_mid_eligible(int B, int H, int W, int K, int N) {
+    return B > 0 && H > 0 && W > 0 && (K == 32 || K == 64 || K == 128) && (N == 32 || N == 64 || N == 128);
+}
+
+int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, int B, int H, int W,
+                       int K, int N, int resample, int epilogue, int out_mode, float slope, float eps, hipStream_t s) {
+    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, ceil_div(W, 16), ceil_div(H, 4), slope, eps};
+    const int n_tiles = B * a.tiles_x * a.tiles_y;
+    const int ns = mid_slice(n_tiles, N);
+    const bool fused = epilogue == 0 || ns == N;
+    const int epi = fused ? epilogue : 0;
+    int st;
+    if (K == 32) st = mid_launch_kg<1>(a, n_tiles, ns, resample, epi, out_mode, s);
+    else if (K == 64) st = mid_launch_kg<2>(a, n_tiles, ns, resample, epi, out_mode, s);
+    else st = mid_launch_kg<4>(a, n_tiles, ns, resample, epi, out_mode, s);
+    if (st || fused) return st;
+    // channels were split over workgroups: LeakyReLU -> PixelNorm over all N channels of a pixel, in place (bias already added)
+    return ngan_lrelu_pixelnorm_fwd(y, nullptr, y, rnorm, (long)B * H * W, N, slope, eps, (void*)s);
+}
+
+int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, char* buf, int len) {
+    const int n_tiles = B * ceil_div(W, 16) * ceil_div(H, 4);
+    const int ns = mid_slice(n_tiles, N);
+    const int epi = (epilogue && ns == N && !out_mode) ? 1 : 0;
+    const int pgw = ns == 128 ? 4 : 2, mtw = ns == 32 ? 1 : 2, wnn = ns == 128 ? 4 : 2;
+    snprintf(buf, len, "conv3x3_mid_kernel<%d, %d, %d, %d, %d, %d>", K / 32, pgw, mtw, wnn, epi, out_mode ? 1 : 0);
+    return NGAN_OK;
+}
+
+}  // namespace ngan

@@ -74,6 +74,12 @@ def test_small_nets_match_reference(ngan, name, conv_precision):
     want_g = split_state(fix, "Ggrad/")
     assert set(dgrads) == set(want_d) and set(ggrads) == set(want_g)
     for k, v in want_d.items():
+        # The critic's last bias gradient is sum_b go[b] with go = -1/B + 2*drift*D(x_b)/B for reals and +1/B for fakes: the
+        # +-1/B terms cancel exactly in real arithmetic and leave ~2e-3 * mean score (~4e-5 at init), so the fp32 rounding of the
+        # individual terms (2B * 2^-24 / B ~ 1e-7, in the reference's own summation order too) is a few 1e-3 of the result.
+        # Its information content (the mean real score) is checked above in `scal`; here it gets that absolute slack.
+        if v.size == 1 and abs(float(dgrads[k].ravel()[0]) - float(v.ravel()[0])) < 5e-7:
+            continue
         assert rel(dgrads[k], v) < 2e-3, ("D", k, rel(dgrads[k], v))
     for k, v in want_g.items():
         assert rel(ggrads[k], v) < 2e-3, ("G", k, rel(ggrads[k], v))

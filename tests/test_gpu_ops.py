@@ -113,6 +113,11 @@ CONV_CASES = [
     (2, 128, 256, 16, 16, 0, True), (2, 128, 256, 32, 16, 0, False), (2, 128, 256, 16, 32, 0, False), (2, 128, 256, 32, 32, 0, True),
     (2, 128, 256, 16, 16, 2, False), (2, 128, 256, 32, 16, 2, False), (2, 128, 256, 32, 32, 2, False),
     (1, 200, 328, 16, 16, 0, False),   # ragged right / bottom edges on the persistent path
+    # split-bf16 kernel for many channels on small images (csrc/conv3x3_mid.hip; exact-fp32 mode runs the generic kernel):
+    # all output channels in one workgroup (fused PixelNorm) for N = 32 / 64 / 128 ...
+    (4, 64, 64, 64, 32, 0, False), (4, 64, 64, 32, 64, 0, True), (4, 64, 64, 32, 128, 0, True),
+    # ... output channels split over workgroups (PixelNorm as a second launch), every K, ragged edges, resampled inputs
+    (8, 16, 16, 128, 128, 0, True), (32, 16, 16, 128, 128, 0, False), (3, 10, 20, 64, 32, 1, False), (2, 12, 20, 128, 64, 2, True),
 ]
 
 
