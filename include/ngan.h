@@ -145,8 +145,8 @@ int ngan_fade_bwd(const float* g, const float* alpha, float* ga, float* gb, long
 int ngan_xhat(const float* real, const float* fake, const float* eps, float* out, int B, long n, void* stream);
 
 /* ---- gradient penalty pieces: loss_functions.py:176 (ATen linalg_vector_norm) ----------------------------------
- * norms[b] = ||g[b,:]||_2 ;   scale_rows: out[b,:] = coef[b] * g[b,:] */
-int ngan_sample_l2norm(const float* g, float* norms, int B, long n, void* stream);
+ * norms[b] = ||g[b,:]||_2 (two fixed-order stages; rows 16-byte aligned, n a multiple of 4);   scale_rows: out[b,:] = coef[b] * g[b,:] */
+int ngan_sample_l2norm(const float* g, float* norms, float* workspace /* 64*B floats */, int B, long n, void* stream);
 int ngan_scale_rows(const float* g, const float* coef, float* out, int B, long n, void* stream);
 
 /* ---- generator stem: Linear_normalized -> Unflatten -> LeakyReLU -> PixelNorm, models.py:299-311 (ATen mm) --------

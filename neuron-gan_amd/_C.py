@@ -35,7 +35,7 @@ SIGNATURES = {
     "ngan_axpby": [_P, _P, _F, _F, _P, _L, _P],
     "ngan_fade_bwd": [_P, _P, _P, _P, _L, _P],
     "ngan_xhat": [_P, _P, _P, _P, _I, _L, _P],
-    "ngan_sample_l2norm": [_P, _P, _I, _L, _P],
+    "ngan_sample_l2norm": [_P, _P, _P, _I, _L, _P],
     "ngan_scale_rows": [_P, _P, _P, _I, _L, _P],
     "ngan_linear_lrelu_pn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P],
     "ngan_linear_wgrad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],

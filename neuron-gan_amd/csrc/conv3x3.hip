@@ -903,8 +903,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int tid = threadIdx.x;
     const long i = (long)blockIdx.x * 16 + (tid & 15);
     float s = 0.f;
-    if (i < M)
-        for (int j = tid >> 4; j < nparts; j += 16) s += partial[(long)j * M + i];
+    if (i < M) {
+        const float* src = partial + i;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = tid >> 4;
+        for (; j + 48 < nparts; j += 64) {
+            a0 += src[(long)j * M]; a1 += src[(long)(j + 16) * M];
+            a2 += src[(long)(j + 32) * M]; a3 += src[(long)(j + 48) * M];
+        }
+        for (; j < nparts; j += 16) a0 += src[(long)j * M];
+        s = (a0 + a1) + (a2 + a3);
+    }
     red[tid] = s;
     __syncthreads();
     if (tid < 16 && i < M) {
@@ -1143,8 +1152,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(ReduceBatch b) {
     float total = 0.f;
     for (int s = 0; s < e.nsrc; ++s) {
         float acc = 0.f;
-        if (i < M)
-            for (int j = tid >> 4; j < e.nparts[s]; j += 16) acc += e.partial[s][(long)j * M + i];
+        if (i < M) {
+            // four independent partial sums: the slab reads of one thread are all in flight instead of one per round trip
+            const float* src = e.partial[s] + i;
+            const int np = e.nparts[s];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int j = tid >> 4;
+            for (; j + 48 < np; j += 64) {
+                a0 += src[(long)j * M]; a1 += src[(long)(j + 16) * M];
+                a2 += src[(long)(j + 32) * M]; a3 += src[(long)(j + 48) * M];
+            }
+            for (; j < np; j += 16) a0 += src[(long)j * M];
+            acc = (a0 + a1) + (a2 + a3);
+        }
         __syncthreads();
         red[tid] = acc;
         __syncthreads();

@@ -18,26 +18,47 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
                                                          float* __restrict__ y, float* __restrict__ rn, int B, int K,
                                                          int S, int C, float scale, float slope, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* z_l = sm;                 // BCH * K   (row b, k contiguous)
-    float* out_l = sm + BCH * K;     // BCH * C
-    float* r_l = out_l + BCH * C;    // BCH
+    // rows of K + 4 floats: the 16 lanes of a ds_read_b128 phase read 16 different samples at the same k, and a pitch of
+    // K floats would put all of them in the same banks (16-way conflict)
+    const int ZP = K + 4, CP = C + 4;
+    float* z_l = sm;                 // BCH * ZP   (row b, k contiguous)
+    float* out_l = sm + BCH * ZP;    // BCH * CP
+    float* r_l = out_l + BCH * CP;   // BCH
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int p = blockIdx.x, b0 = blockIdx.y * BCH;
     const int nb = min(BCH, B - b0);
-    for (int e = tid; e < BCH * K; e += 256) {
-        const int bb = e / K;
-        z_l[e] = bb < nb ? z[(long)(b0 + bb) * K + (e - bb * K)] * scale : 0.f;   // weight_scale * x, models.py:241
-    }
+    for (int bb = tid >> 4; bb < BCH; bb += 16)
+        for (int k = (tid & 15) * 4; k < K; k += 64) {
+            const float4 v = bb < nb ? ld4(z + (long)(b0 + bb) * K + k) : f4zero();
+            st4(z_l + bb * ZP + k, f4scale(v, scale));                            // weight_scale * x, models.py:241
+        }
     __syncthreads();
     const int ntile = (C + 15) >> 4, ksteps = K >> 4;
     for (int ct = wave; ct < ntile; ct += 4) {
         const int c = ct * 16 + j;
         const float* wrow = Wt + ((long)min(c, C - 1) * S + p) * K + q * 4;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < ksteps; ++s) {
-            const float4 wv = ld4(wrow + s * 16);                      // W[row c][16s + 4q .. +3]
-            const float4 zv = ld4(z_l + j * K + s * 16 + q * 4);       // z[sample j][16s + 4q .. +3]
+        // the weight row is read once from HBM: keep UNR 16-byte loads per lane in flight (one load per MFMA group left the
+        // wave waiting a full memory round trip every 4 MFMAs: 45 us for the 67 MB default stem instead of ~15)
+        constexpr int UNR = 16;
+        int s = 0;
+        for (; s + UNR <= ksteps; s += UNR) {
+            float4 wv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) wv[u] = ld4(wrow + (s + u) * 16);     // W[row c][16(s+u) + 4q .. +3]
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const float4 zv = ld4(z_l + j * ZP + (s + u) * 16 + q * 4);       // z[sample j][16(s+u) + 4q .. +3]
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.x, wv[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.y, wv[u].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.z, wv[u].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.w, wv[u].w, acc, 0, 0, 0);
+            }
+        }
+        for (; s < ksteps; ++s) {
+            const float4 wv = ld4(wrow + s * 16);
+            const float4 zv = ld4(z_l + j * ZP + s * 16 + q * 4);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.x, wv.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.y, wv.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zv.z, wv.z, acc, 0, 0, 0);
@@ -47,37 +68,102 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = acc[r];
-                out_l[(4 * q + r) * C + c] = v > 0.f ? v : slope * v;
+                out_l[(4 * q + r) * CP + c] = v > 0.f ? v : slope * v;
             }
         }
     }
     __syncthreads();
-    if (tid < nb) {
+    {   // PixelNorm over the C channels of each sample: 16 lanes per sample
+        const int bb = tid >> 4, part = tid & 15;
         float ss = 0.f;
-        for (int c = 0; c < C; ++c) ss = fmaf(out_l[tid * C + c], out_l[tid * C + c], ss);
-        const float r = sqrtf(ss / (float)C + eps);
-        r_l[tid] = r;
-        rn[(long)(b0 + tid) * S + p] = r;
+        for (int c = part; c < C; c += 16) ss = fmaf(out_l[bb * CP + c], out_l[bb * CP + c], ss);
+        ss = group_sum<16>(ss);
+        if (part == 0 && bb < nb) {
+            const float r = sqrtf(ss / (float)C + eps);
+            r_l[bb] = r;
+            rn[(long)(b0 + bb) * S + p] = r;
+        }
     }
     __syncthreads();
-    for (int e = tid; e < nb * C; e += 256) {
-        const int bb = e / C, c = e - bb * C;
-        y[((long)(b0 + bb) * S + p) * C + c] = out_l[e] / r_l[bb];
+    for (int bb = tid >> 4; bb < nb; bb += 16) {
+        const float inv = 1.0f / r_l[bb];
+        for (int c = tid & 15; c < C; c += 16) y[((long)(b0 + bb) * S + p) * C + c] = out_l[bb * CP + c] * inv;
     }
 }
 
-// gW[c*S+p][k] = scale * sum_b gc[b][p][c] * z[b][k]; one thread per (row, k-quad)
+// gW[c*S+p][k] = scale * sum_b gc[b][p][c] * z[b][k].  The output (67 MB for the default stem) is written once; a thread owns one
+// k-quad and keeps z[b][k-quad] for a chunk of WB samples in registers, a wave walks weight rows, so gc[b][row] is the same
+// for all of its lanes (one broadcast load) and a row costs WB x 4 FMAs per lane and one 16-byte store.
+constexpr int WB = 16;
+
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ z, const float* __restrict__ gc,
-                                                           float* __restrict__ gW, int B, int K, int S, int C, float scale) {
+                                                           float* __restrict__ gW, int B, int K, int S, int C, float scale,
+                                                           int rows_per_block) {
     const int K4 = K >> 2;
-    const long total = (long)C * S * K4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k4 = (int)(i % K4);
-        const long j = i / K4;
-        const int p = (int)(j % S), c = (int)(j / S);
-        float4 acc = f4zero();
-        for (int b = 0; b < B; ++b) acc = f4fma(ld4(z + (long)b * K + k4 * 4), gc[((long)b * S + p) * C + c], acc);
-        st4(gW + j * K + k4 * 4, f4scale(acc, scale));
+    const int tid = threadIdx.x;
+    const int wpr = (K4 + 63) >> 6;                     // waves per weight row
+    const int wave = tid >> 6, lane = tid & 63;
+    const int k4 = (wave % wpr) * 64 + lane;            // this lane's k-quad
+    const int rsub = wave / wpr, rstep = 4 / wpr;       // rows are dealt to the block's wave groups
+    const bool act = k4 < K4 && rsub < rstep;
+    const long rows = (long)C * S;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int b0 = 0; b0 < B; b0 += WB) {
+        float4 zr[WB];
+#pragma unroll
+        for (int i = 0; i < WB; ++i) zr[i] = (act && b0 + i < B) ? ld4(z + (long)(b0 + i) * K + k4 * 4) : f4zero();
+        for (long j = r0 + rsub; j < r1; j += rstep) {
+            const int p = (int)(j % S), c = (int)(j / S);
+            float4 acc = f4zero();
+#pragma unroll
+            for (int i = 0; i < WB; ++i) {
+                const float gv = (b0 + i < B) ? gc[((long)(b0 + i) * S + p) * C + c] : 0.f;     // wave-uniform address
+                acc = f4fma(zr[i], gv, acc);
+            }
+            if (act) {
+                float* o = gW + j * K + k4 * 4;
+                if (b0 == 0) st4(o, f4scale(acc, scale));
+                else st4(o, f4fma(acc, scale, ld4(o)));
+            }
+        }
+    }
+}
+
+// MFMA form of the same contraction for K <= 512 (the contraction index is the SAMPLE, any B in one pass -- the data-parallel
+// stem exchange forms the full-batch gradient from world*B gathered samples): a wave owns 16 weight rows and all K columns,
+// A = z^T (16 k-columns x 4 samples), B = gc (4 samples x 16 rows), so a lane ends with 4 consecutive k of one row: one
+// 16-byte store.  z (B x K) and gc are tiny and stay in L1/L2; the 4*C*S*K-byte result is written exactly once.
+template <int NT>
+__global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __restrict__ z, const float* __restrict__ gc,
+                                                                float* __restrict__ gW, int B, int K, int S, int C, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const long rows = (long)C * S;
+    const long row = ((long)blockIdx.x * 4 + wave) * 16 + m;            // this lane's weight row (as B-operand column)
+    const bool rok = row < rows;
+    const int p = (int)(row % S), c = (int)(row / S);
+    const int nt = K >> 4;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < B; b0 += 4) {
+        const int b = b0 + kq;
+        const bool bok = b < B;
+        const float gv = (rok && bok) ? gc[((long)b * S + p) * C + c] : 0.f;
+        const float* zr = z + (long)(bok ? b : 0) * K + m;
+        float zv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) zv[t] = (bok && t < nt) ? zr[t * 16] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[t], gv, acc[t], 0, 0, 0);
+    }
+    if (rok) {
+        float* o = gW + row * K + kq * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < nt) st4(o + t * 16, make_float4(acc[t][0] * scale, acc[t][1] * scale, acc[t][2] * scale, acc[t][3] * scale));
     }
 }
 
@@ -94,23 +180,52 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
 }
 
 // ---- critic head ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void final_dot_fwd_kernel(const float* __restrict__ y, const float* __restrict__ W,
-                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                            int S2, int C, float scale) {
-    __shared__ float red[4];
+// One block per sample.  y is (S2, C) channels-last, W is (C, S2): the block first copies W into LDS transposed ([p][c], pitch
+// C + 1) with coalesced global reads, then both operands of the dot product are contiguous.  (Gathering W with stride S2 per
+// lane instead costs one cache line per lane per load: 23 us for a 2 MB input.)
+__global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const float* __restrict__ y, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int S2, int C, float scale, int use_lds) {
+    extern __shared__ float wt[];
+    __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const long n = (long)S2 * C;
+    const int n = S2 * C;
     const float* yb = y + (long)b * n;
     float s = 0.f;
-    for (long e = tid; e < n; e += 256) {
-        const int c = (int)(e % C);
-        const int p = (int)(e / C);
-        s = fmaf(yb[e], W[(long)c * S2 + p], s);
+    if (use_lds) {
+        const int CP = C + 1;
+        for (int e = tid; e < n; e += 1024) {
+            const int c = e / S2, p = e - c * S2;
+            wt[p * CP + c] = W[e];
+        }
+        __syncthreads();
+        float a0 = 0.f, a1 = 0.f;
+        int e = tid;
+        for (; e + 1024 < n; e += 2048) {
+            const int p0 = e / C, c0 = e - p0 * C, p1 = (e + 1024) / C, c1 = e + 1024 - p1 * C;
+            a0 = fmaf(yb[e], wt[p0 * CP + c0], a0);
+            a1 = fmaf(yb[e + 1024], wt[p1 * CP + c1], a1);
+        }
+        if (e < n) {
+            const int p0 = e / C, c0 = e - p0 * C;
+            a0 = fmaf(yb[e], wt[p0 * CP + c0], a0);
+        }
+        s = a0 + a1;
+    } else {
+        for (int e = tid; e < n; e += 1024) {
+            const int p = e / C, c = e - p * C;
+            s = fmaf(yb[e], W[(long)c * S2 + p], s);
+        }
     }
     s = group_sum<64>(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) out[b] = ((red[0] + red[1]) + (red[2] + red[3])) * scale + (bias ? bias[0] : 0.f);
+    if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i];
+        out[b] = t * scale + (bias ? bias[0] : 0.f);
+    }
 }
 
 __global__ void final_dot_dx_kernel(const float* __restrict__ go, const float* __restrict__ W, float* __restrict__ gy,
@@ -154,7 +269,8 @@ extern "C" int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* 
     NGAN_REQUIRE(z && Wt && y && rnorm, NGAN_ERR_ARG, "linear_lrelu_pn_fwd: null pointer");
     NGAN_REQUIRE(B > 0 && K > 0 && K % 16 == 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: B=%d K=%d (multiple of 16) S=%d C=%d unsupported",
                  B, K, S, C);
-    const size_t lds = (size_t)(BCH * K + BCH * C + BCH) * sizeof(float);
+    NGAN_REQUIRE(K % 4 == 0, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: K=%d must be a multiple of 4", K);
+    const size_t lds = (size_t)(BCH * (K + 4) + BCH * (C + 4) + BCH) * sizeof(float);
     NGAN_REQUIRE(lds <= 64 * 1024, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: K=%d C=%d need %zu B of LDS", K, C, lds);
     hipLaunchKernelGGL(linear_fwd_kernel, dim3(S, ngan::ceil_div(B, BCH)), dim3(256), lds, (hipStream_t)stream, z, Wt, y, rnorm,
                        B, K, S, C, scale, slope, eps);
@@ -164,8 +280,17 @@ extern "C" int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* 
 extern "C" int ngan_linear_wgrad(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale, void* stream) {
     NGAN_REQUIRE(z && gc && gW, NGAN_ERR_ARG, "linear_wgrad: null pointer");
     NGAN_REQUIRE(B > 0 && K > 0 && K % 4 == 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_wgrad: B=%d K=%d S=%d C=%d unsupported", B, K, S, C);
-    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(ew_blocks((long)C * S * (K / 4))), dim3(256), 0, (hipStream_t)stream, z, gc, gW,
-                       B, K, S, C, scale);
+    NGAN_REQUIRE(K / 4 <= 256, NGAN_ERR_SHAPE, "linear_wgrad: K=%d must be at most 1024", K);
+    const long rows = (long)C * S;
+    if (K % 16 == 0 && K <= 512) {
+        const dim3 grid(ngan::ceil_div(rows, 64)), block(256);
+        if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<8>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale);
+        else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<32>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale);
+        return ngan::launch_status("ngan_linear_wgrad(mfma)");
+    }
+    const int rpb = rows >= 4096 ? 16 : 4;
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(ngan::ceil_div(rows, rpb)), dim3(256), 0, (hipStream_t)stream, z, gc, gW,
+                       B, K, S, C, scale, rpb);
     return ngan::launch_status("ngan_linear_wgrad");
 }
 
@@ -179,7 +304,15 @@ extern "C" int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, in
 extern "C" int ngan_final_dot_fwd(const float* y, const float* W, const float* bias, float* out, int B, int S2, int C, float scale,
                                   void* stream) {
     NGAN_REQUIRE(y && W && out && B > 0 && S2 > 0 && C > 0, NGAN_ERR_ARG, "final_dot_fwd: bad argument");
-    hipLaunchKernelGGL(final_dot_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y, W, bias, out, S2, C, scale);
+    const size_t lds = (size_t)S2 * (C + 1) * sizeof(float);
+    const int use_lds = lds <= 150 * 1024;
+    static bool attr_set = false;
+    if (use_lds && lds > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(final_dot_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        NGAN_REQUIRE(e == hipSuccess, (int)e, "final_dot_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(final_dot_fwd_kernel, dim3(B), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, y, W, bias, out, S2, C, scale, use_lds);
     return ngan::launch_status("ngan_final_dot_fwd");
 }
 

@@ -6,28 +6,36 @@
 
 namespace ngan {
 
-// out[i] = scale * sum_j partials[j*stride + i], i < M.  Fixed summation order (deterministic).
-// 16 outputs x 16 part-lanes per block so that short outputs (a bias: 16 floats) still spread over many lanes.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int M,
-                                                              long stride, float* __restrict__ out, float scale) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    const long i = (long)blockIdx.x * 16 + (tid & 15);
-    float s = 0.f;
-    if (i < M)
-        for (int j = tid >> 4; j < nparts; j += 16) s += partials[(long)j * stride + i];
-    red[tid] = s;
-    __syncthreads();
-    if (tid < 16 && i < M) {
-        s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) s += red[tid + 16 * j];
-        out[i] = s * scale;
+// out[i] = scale * sum_j partials[j*stride + i], i < M (outputs i >= M1 go to out2[i - M1]).  One wave per output: lane l adds
+// parts l, l + 64, ... (independent loads, all in flight), then a butterfly over the wave: fixed order, deterministic.
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int M,
+                                                             long stride, float* __restrict__ out, int M1,
+                                                             float* __restrict__ out2, float scale) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int j = lane;
+    for (; j + 192 < nparts; j += 256) {
+        s0 += partials[(long)j * stride + i];
+        s1 += partials[(long)(j + 64) * stride + i];
+        s2 += partials[(long)(j + 128) * stride + i];
+        s3 += partials[(long)(j + 192) * stride + i];
+    }
+    for (; j < nparts; j += 64) s0 += partials[(long)j * stride + i];
+    const float s = group_sum<64>((s0 + s1) + (s2 + s3));
+    if (lane == 0) {
+        if (i < M1) out[i] = s * scale;
+        else out2[i - M1] = s * scale;
     }
 }
 
 int reduce_partials_strided(const float* partials, int nparts, int M, long stride, float* out, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(M, 16)), dim3(256), 0, s, partials, nparts, M, stride, out, scale);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(M), dim3(64), 0, s, partials, nparts, M, stride, out, M, (float*)nullptr, scale);
+    return launch_status("reduce_partials");
+}
+
+int reduce_partials_split(const float* partials, int nparts, int M, long stride, float* out, int M1, float* out2, float scale,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(M), dim3(64), 0, s, partials, nparts, M, stride, out, M1, out2, scale);
     return launch_status("reduce_partials");
 }
 
@@ -40,7 +48,7 @@ int reduce_partials(const float* partials, int nparts, int M, float* out, float 
 namespace {
 
 using ngan::ceil_div;
-constexpr int MAX_PARTS = 512;
+constexpr int MAX_PARTS = 1024;   // callers size their slab workspaces for 1024 parts
 
 bool pow2_quads(int C) {
     if (C <= 0 || C % 4) return false;
@@ -97,36 +105,38 @@ template <int POOL>
 __global__ __launch_bounds__(256) void from_image_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              int B, int H, int W, int Ncol, int C) {
-    const int Q = C / 4;
-    const long total = (long)B * H * W * Q;
-    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
-        const long pix = gid / Q;
-        const int c0 = (int)(gid % Q) * 4;
-        const int xx = (int)(pix % W);
-        const int yy = (int)((pix / W) % H);
-        const int b = (int)(pix / ((long)W * H));
+    const unsigned Q = C / 4;
+    const unsigned total = (unsigned)B * H * W * Q;       // host checks that this fits 31 bits
+    for (unsigned gid = blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += gridDim.x * blockDim.x) {
+        const unsigned pix = gid / Q;
+        const int c0 = (int)(gid - pix * Q) * 4;
+        const unsigned row = pix / (unsigned)W;
+        const int xx = (int)(pix - row * W);
+        const int b = (int)(row / (unsigned)H);
+        const int yy = (int)(row - (unsigned)b * H);
         float4 o = bias ? ld4(bias + c0) : f4zero();
         for (int k = 0; k < Ncol; ++k) {
             const float v = load_img<POOL>(x, b, yy, xx, k, H, W, Ncol);
             o.x = fmaf(w[(c0 + 0) * Ncol + k], v, o.x); o.y = fmaf(w[(c0 + 1) * Ncol + k], v, o.y);
             o.z = fmaf(w[(c0 + 2) * Ncol + k], v, o.z); o.w = fmaf(w[(c0 + 3) * Ncol + k], v, o.w);
         }
-        st4(y + pix * C + c0, o);
+        st4(y + (long)pix * C + c0, o);
     }
 }
 
 template <int Q, int POOL>
 __global__ __launch_bounds__(256) void from_image_dx_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                             float* __restrict__ gx, int B, int H, int W, int Ncol, int C) {
-    const long npix = (long)B * H * W;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long pix = gid / Q;
+    const unsigned npix = (unsigned)B * H * W;            // host checks that npix * Q fits 31 bits
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned pix = gid / Q;
     const int sub = (int)(gid % Q);
     const bool ok = pix < npix;
-    const float4 gv = ok ? ld4(g + pix * C + sub * 4) : f4zero();
-    const int xx = (int)(pix % W);
-    const int yy = (int)((pix / W) % H);
-    const int b = (int)(pix / ((long)W * H));
+    const float4 gv = ok ? ld4(g + (long)pix * C + sub * 4) : f4zero();
+    const unsigned row = pix / (unsigned)W;
+    const int xx = (int)(pix - row * W);
+    const int b = (int)(row / (unsigned)H);
+    const int yy = (int)(row - (unsigned)b * H);
     for (int k = 0; k < Ncol; ++k) {
         const int c0 = sub * 4;
         float part = gv.x * w[(c0 + 0) * Ncol + k] + gv.y * w[(c0 + 1) * Ncol + k] + gv.z * w[(c0 + 2) * Ncol + k] +
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(256) void from_image_dx_kernel(const float* __restr
         const float s = group_sum<Q>(part);
         if (ok && sub == 0) {
             if (POOL == 0) {
-                gx[pix * Ncol + k] = s;
+                gx[(long)pix * Ncol + k] = s;
             } else {
                 const long W2 = 2L * W;
                 float* p = gx + (((long)b * 2 * H + 2 * yy) * W2 + 2 * xx) * Ncol + k;
@@ -151,20 +161,35 @@ __global__ __launch_bounds__(256) void from_image_dw_kernel(const float* __restr
                                                             float* __restrict__ partial, int B, int H, int W, int Ncol, int C) {
     __shared__ float4 red[256];
     const int tid = threadIdx.x, sub = tid % Q;
-    const long npix = (long)B * H * W;
-    const long stride = (long)gridDim.x * (256 / Q);
+    const unsigned npix = (unsigned)B * H * W;            // host checks that npix fits 31 bits
+    const unsigned stride = gridDim.x * (256 / Q);
     float4 acc[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) acc[k] = f4zero();
-    for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) {
-        const float4 gv = ld4(g + pix * C + sub * 4);
-        const int xx = (int)(pix % W);
-        const int yy = (int)((pix / W) % H);
-        const int b = (int)(pix / ((long)W * H));
-        acc[4] = f4add(acc[4], gv);
+    // 4 pixels per iteration with every load issued before the first use: the loop is a latency chain otherwise
+    for (unsigned pix0 = blockIdx.x * (256 / Q) + tid / Q; pix0 < npix; pix0 += 4 * stride) {
+        float4 gv[4];
+        float xv[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < Ncol) acc[k] = f4fma(gv, load_img<POOL>(x, b, yy, xx, k, H, W, Ncol), acc[k]);
+        for (int u = 0; u < 4; ++u) {
+            const unsigned pu = pix0 + u * stride;
+            const unsigned pix = pu < npix ? pu : npix - 1;
+            gv[u] = ld4(g + (long)pix * C + sub * 4);
+            const unsigned row = pix / (unsigned)W;
+            const int xx = (int)(pix - row * W);
+            const int b = (int)(row / (unsigned)H);
+            const int yy = (int)(row - (unsigned)b * H);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[u][k] = k < Ncol ? load_img<POOL>(x, b, yy, xx, k, H, W, Ncol) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (pix0 + u * stride >= npix) gv[u] = f4zero();
+            acc[4] = f4add(acc[4], gv[u]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < Ncol) acc[k] = f4fma(gv[u], xv[u][k], acc[k]);
+        }
     }
     float* slab = partial + (long)blockIdx.x * C * (Ncol + 1);
 #pragma unroll
@@ -387,20 +412,35 @@ __global__ void scale_rows_kernel(const float* __restrict__ g, const float* __re
         out[base + i] = c * g[base + i];
 }
 
-__global__ __launch_bounds__(1024) void sample_l2norm_kernel(const float* __restrict__ g, float* __restrict__ norms, long n) {
-    __shared__ float red[16];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// per-sample L2 norm in two fixed-order stages: NCHUNK blocks per sample write partial sums of squares (16-byte loads, 4
+// independent accumulators per thread), one wave per sample adds them and takes the root
+constexpr int L2_CHUNKS = 64;
+
+__global__ __launch_bounds__(256) void sample_sumsq_kernel(const float* __restrict__ g, float* __restrict__ partial, long n) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, tid = threadIdx.x;
     const float* p = g + (long)b * n;
-    float s = 0.f;
-    for (long i = tid; i < n; i += 1024) s = fmaf(p[i], p[i], s);
+    const long n4 = n >> 2;
+    float4 a = f4zero();
+    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = ld4(p + i * 4);
+        a.x = fmaf(v.x, v.x, a.x); a.y = fmaf(v.y, v.y, a.y); a.z = fmaf(v.z, v.z, a.z); a.w = fmaf(v.w, v.w, a.w);
+    }
+    float s = (a.x + a.y) + (a.z + a.w);
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + tid; i < n; i += 256) s = fmaf(p[i], p[i], s);      // tail when n is not a multiple of 4
     s = group_sum<64>(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int i = 0; i < 16; ++i) t += red[i];
-        norms[b] = sqrtf(t);
-    }
+    if (tid == 0) partial[(long)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void sample_l2norm_finish_kernel(const float* __restrict__ partial, float* __restrict__ norms, int nchunk) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < nchunk; i += 64) s += partial[(long)b * nchunk + i];
+    s = group_sum<64>(s);
+    if (tid == 0) norms[b] = sqrtf(s);
 }
 
 int ew_blocks(long n) {
@@ -439,6 +479,7 @@ extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* 
     NGAN_REQUIRE(x && w && y, NGAN_ERR_ARG, "from_image_fwd: null pointer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0, NGAN_ERR_SHAPE,
                  "from_image_fwd: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
+    NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_fwd: B*H*W*C/4 must be below 2^31");
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ew_blocks((long)B * H * W * (C / 4));
     if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<1>), dim3(nblk), dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
@@ -451,6 +492,7 @@ extern "C" int ngan_from_image_dx(const float* g, const float* w, float* gx, int
     NGAN_REQUIRE(g && w && gx, NGAN_ERR_ARG, "from_image_dx: null pointer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
                  "from_image_dx: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
+    NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_dx: B*H*W*C/4 must be below 2^31");
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div((long)B * H * W * (C / 4), 256);
 #define CALL(QV)                                                                                                     \
@@ -466,6 +508,7 @@ extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, flo
     NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "from_image_dw: null pointer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
                  "from_image_dw: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
+    NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_dw: B*H*W*C/4 must be below 2^31");
     hipStream_t s = (hipStream_t)stream;
     const int nblk = stream_blocks((long)B * H * W, C / 4);
 #define CALL(QV)                                                                                                              \
@@ -476,9 +519,8 @@ extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, flo
     int st = ngan::launch_status("ngan_from_image_dw");
     if (st) return st;
     const long stride = (long)C * (Ncol + 1);
-    st = ngan::reduce_partials_strided(workspace, nblk, C * Ncol, stride, gw, 1.0f, s);
-    if (st || !gb) return st;
-    return ngan::reduce_partials_strided(workspace + (long)C * Ncol, nblk, C, stride, gb, 1.0f, s);
+    if (!gb) return ngan::reduce_partials_strided(workspace, nblk, C * Ncol, stride, gw, 1.0f, s);
+    return ngan::reduce_partials_split(workspace, nblk, C * (Ncol + 1), stride, gw, C * Ncol, gb, 1.0f, s);   // weight and bias sums: one launch
 }
 
 extern "C" int ngan_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, void* stream) {
@@ -565,8 +607,12 @@ extern "C" int ngan_scale_rows(const float* g, const float* coef, float* out, in
     return ngan::launch_status("ngan_scale_rows");
 }
 
-extern "C" int ngan_sample_l2norm(const float* g, float* norms, int B, long n, void* stream) {
-    NGAN_REQUIRE(g && norms && B > 0 && n > 0, NGAN_ERR_ARG, "sample_l2norm: bad argument");
-    hipLaunchKernelGGL(sample_l2norm_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, g, norms, n);
+extern "C" int ngan_sample_l2norm(const float* g, float* norms, float* workspace, int B, long n, void* stream) {
+    NGAN_REQUIRE(g && norms && workspace && B > 0 && n > 0, NGAN_ERR_ARG, "sample_l2norm: bad argument");
+    NGAN_REQUIRE(((size_t)g & 15) == 0 && (n % 4 == 0 || B == 1), NGAN_ERR_SHAPE, "sample_l2norm: rows must be 16-byte aligned (n=%ld)", n);
+    long want = (n / 4 + 255) / 256;
+    const int nchunk = (int)(want < 1 ? 1 : (want > L2_CHUNKS ? L2_CHUNKS : want));
+    hipLaunchKernelGGL(sample_sumsq_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, g, workspace, n);
+    hipLaunchKernelGGL(sample_l2norm_finish_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, workspace, norms, nchunk);
     return ngan::launch_status("ngan_sample_l2norm");
 }

@@ -783,7 +783,8 @@ class SampleL2Norm(Function):
         g = _c(g)
         b = g.shape[0]
         norms = torch.empty(b, device=g.device, dtype=torch.float32)
-        _C.call("ngan_sample_l2norm", g, norms, b, g.numel() // b)
+        ws = torch.empty(64 * b, device=g.device, dtype=torch.float32)
+        _C.call("ngan_sample_l2norm", g, norms, ws, b, g.numel() // b)
         ctx.save_for_backward(g, norms)
         return norms
 

@@ -237,7 +237,7 @@ def test_final_dot_all_orders(ngan):
              lambda d: torch.tanh(F.conv2d(scale * d["x"], d["w"], d["b"]).flatten(1)), t, ["w", "b"], x_name="x")
 
 
-@pytest.mark.parametrize("B,K,S,C", [(3, 32, 4, 32), (20, 512, 16, 128)])
+@pytest.mark.parametrize("B,K,S,C", [(3, 32, 4, 32), (20, 512, 16, 128), (37, 768, 4, 32)])   # MFMA wgrad (K <= 512) / row-streaming wgrad
 def test_linear_stem(ngan, B, K, S, C):
     ops = ngan.ops
     torch.manual_seed(8)
@@ -255,10 +255,11 @@ def test_linear_stem(ngan, B, K, S, C):
     run_both(f_hip, f_ref, t, ["z", "w"])
 
 
-def test_sample_l2norm(ngan):
+@pytest.mark.parametrize("shape", [(4, 1, 32, 32), (3, 1, 6, 6), (16, 1, 512, 512)])
+def test_sample_l2norm(ngan, shape):
     ops = ngan.ops
     torch.manual_seed(9)
-    t = {"g": torch.randn(4, 1, 32, 32)}
+    t = {"g": torch.randn(*shape)}
     run_both(lambda d: ops.SampleL2Norm.apply(d["g"]), lambda d: d["g"].norm(2, dim=(1, 2, 3)), t, ["g"])
 
 
