@@ -773,24 +773,35 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base_lo16, const __bf16*
     return r;
 }
 
-template <int COT, int CIT, int RES>
+template <int COT, int CIT, int RES, int TW>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
-    constexpr int TW = 32, TH = 8, HALO_H = TH + 2, HALO_W = TW + 2, G_PIX = TH * TW, X_PIX = HALO_H * HALO_W;
+    // tile = 256 pixels: 8 x 32, or 16 x 16 for images at most 16 wide.  One k-step = 32 pixels = one tile row (TW = 32) or two
+    // consecutive rows (TW = 16): the second 16-pixel half of a fragment then sits one halo row further instead of 16 pixels.
+    constexpr int TH = 256 / TW, HALO_H = TH + 2, HALO_W = TW + 2, G_PIX = TH * TW, X_PIX = HALO_H * HALO_W;
     constexpr int CO_S = COT * 16, CI_S = CIT * 16;
-    constexpr int WO = COT * CIT, WR = 4 / WO, RPW = TH / WR;
-    constexpr int G_E = 2 * COT * G_PIX * 16, X_E = 2 * CIT * X_PIX * 16;       // bf16 elements
+    constexpr int WO = COT * CIT, WR = 4 / WO, NKS = 8, KPW = NKS / WR;          // k-steps per tile / per wave
+    constexpr int X_HALF2 = (TW == 32 ? 16 : HALO_W) * 16;                       // bf16 offset of a fragment's second half in x
+    constexpr int X_ROWS_PER_KS = TW == 32 ? 1 : 2;
+    constexpr int G_E = 2 * COT * G_PIX * 16, X_E = 2 * CIT * X_PIX * 16;        // bf16 elements
+    // bilinear input: the low-resolution source patch is staged once (fp32) and expanded LDS -> LDS, as in conv3x3_persist_kernel
+    constexpr int PH = TH / 2 + 2, PW = TW / 2 + 2, NPP = PH * PW;
+    constexpr int PATCH_BYTES = RES == NGAN_RESAMPLE_UP2 ? NPP * CI_S * 4 : 0;
     constexpr int RED_BYTES = 4 * 9 * 64 * 16;
-    constexpr int SMEM_BYTES = (G_E + X_E) * 2 > RED_BYTES ? (G_E + X_E) * 2 : RED_BYTES;
+    constexpr int IMG_BYTES = (G_E + X_E) * 2 + PATCH_BYTES;
+    constexpr int SMEM_BYTES = IMG_BYTES > RED_BYTES ? IMG_BYTES : RED_BYTES;
     constexpr int NG = G_PIX * (CO_S / 4) / 256, NXI = X_PIX * (CI_S / 4), NX = (NXI + 255) / 256;
+    constexpr int NPI = NPP * (CI_S / 4), NXL = RES == NGAN_RESAMPLE_UP2 ? (NPI + 255) / 256 : NX;   // global loads per thread for x
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
     __bf16* g_img = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* x_img = g_img + G_E;
+    float* patch = reinterpret_cast<float*>(smem_raw + (G_E + X_E) * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
     const int wo = wave % WO, wr = wave / WO;
     const int cot = wo / CIT, cit = wo % CIT;
     const int slice = blockIdx.y;
     const int co0 = (slice / a.n_ci_slices) * CO_S, ci0 = (slice % a.n_ci_slices) * CI_S;
+    const int h = a.H >> 1, w = a.W >> 1;
 
     int g_r[NG], g_c[NG], g_ch[NG], g_l[NG];
 #pragma unroll
@@ -800,6 +811,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         g_r[i] = pix / TW; g_c[i] = pix % TW; g_ch[i] = co0 + c4 * 4;
         g_l[i] = ((c4 >> 2) * G_PIX + pix) * 16 + (c4 & 3) * 4;                 // hi part; lo = + COT*G_PIX*16
     }
+    // x staging descriptors: halo pixel (row, col) relative to the tile origin, channel, bf16 index of the hi part
     int x_r[NX], x_c[NX], x_ch[NX], x_l[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -815,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 gst[NG], xst[NX];
+    float4 gst[NG], xst[NXL];
     auto issue = [&](int tile) {
         int t = tile;
         const int txi = t % a.tiles_x; t /= a.tiles_x;
@@ -828,9 +840,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
             const int gy = y0 + g_r[i], gx = x0 + g_c[i];
             gst[i] = (gy < a.H && gx < a.W) ? ld4(gb + ((long)gy * a.W + gx) * a.N + g_ch[i]) : f4zero();
         }
+        if (RES == NGAN_RESAMPLE_UP2) {
+            const float* xb = a.x + (long)b * h * w * a.K;
+            const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
-            xst[i] = x_r[i] > -1000 ? load_resampled<RES>(a.x, b, y0 + x_r[i], x0 + x_c[i], x_ch[i], a.H, a.W, a.K) : f4zero();
+            for (int i = 0; i < NXL; ++i) {
+                const int e = tid + i * 256;
+                const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
+                const int ly = min(max(ly0 + pix / PW, 0), h - 1), lx = min(max(lx0 + pix % PW, 0), w - 1);
+                xst[i] = e < NPI ? ld4(xb + ((long)ly * w + lx) * a.K + ci0 + c4 * 4) : f4zero();
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NXL; ++i)
+                xst[i] = x_r[i] > -1000 ? load_resampled<RES>(a.x, b, y0 + x_r[i], x0 + x_c[i], x_ch[i], a.H, a.W, a.K) : f4zero();
+        }
     };
     auto split_store = [&](__bf16* img, int idx, int lo_off, float4 v) {
         bf16x4 hi, lo;
@@ -847,9 +871,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NG; ++i) split_store(g_img, g_l[i], COT * G_PIX * 16, gst[i]);
+        if (RES == NGAN_RESAMPLE_UP2) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
-            if (x_r[i] > -1000) split_store(x_img, x_l[i], CIT * X_PIX * 16, xst[i]);
+            for (int i = 0; i < NXL; ++i)
+                if (tid + i * 256 < NPI) st4(patch + (tid + i * 256) * 4, xst[i]);       // patch is plain [py][px][CI_S]
+            __syncthreads();
+            int t = tile;
+            const int txi = t % a.tiles_x; t /= a.tiles_x;
+            const int tyi = t % a.tiles_y;
+            const int y0 = tyi * TH, x0 = txi * TW;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                if (x_r[i] <= -1000) continue;
+                const int Y = y0 + x_r[i], X = x0 + x_c[i];
+                float4 v = f4zero();
+                if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
+                    // Y odd -> taps (i, i+1), weights (.75, .25); Y even -> taps (i-1, i), weights (.25, .75); patch row 0 is low-res
+                    // row y0/2 - 1 (loaded with clamped coordinates, so the image border needs no special case)
+                    const float wy0 = (Y & 1) ? 0.75f : 0.25f, wx0 = (X & 1) ? 0.75f : 0.25f;
+                    const int ry = (x_r[i] + 1) >> 1, rx = (x_c[i] + 1) >> 1;
+                    const float* r0 = patch + (ry * PW + rx) * CI_S + (x_ch[i] - ci0);
+                    const float4 top = f4fma(ld4(r0 + CI_S), 1.0f - wx0, f4scale(ld4(r0), wx0));
+                    const float4 bot = f4fma(ld4(r0 + PW * CI_S + CI_S), 1.0f - wx0, f4scale(ld4(r0 + PW * CI_S), wx0));
+                    v = f4fma(bot, 1.0f - wy0, f4scale(top, wy0));
+                }
+                split_store(x_img, x_l[i], CIT * X_PIX * 16, v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                if (x_r[i] > -1000) split_store(x_img, x_l[i], CIT * X_PIX * 16, xst[i]);
+        }
         __syncthreads();
         const int tn = tile + gridDim.x;
         if (tn < a.n_tiles) issue(tn);
@@ -857,16 +909,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         const __bf16* gl = gh + COT * G_PIX * 16;
         const __bf16* xh = x_img + cit * X_PIX * 16 + tr0;
         const __bf16* xl = xh + CIT * X_PIX * 16;
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wr * RPW + rr;
-            const bf16x8 ah = tr_frag(gh + r * TW * 16, gh + (r * TW + 16) * 16);
-            const bf16x8 al = tr_frag(gl + r * TW * 16, gl + (r * TW + 16) * 16);
+        for (int kk = 0; kk < KPW; ++kk) {
+            const int ks = wr * KPW + kk;
+            const bf16x8 ah = tr_frag(gh + ks * 32 * 16, gh + (ks * 32 + 16) * 16);
+            const bf16x8 al = tr_frag(gl + ks * 32 * 16, gl + (ks * 32 + 16) * 16);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap % 3;
-                const int xo = ((r + dy) * HALO_W + dx) * 16;
-                const bf16x8 bh = tr_frag(xh + xo, xh + xo + 256);
-                const bf16x8 bl = tr_frag(xl + xo, xl + xo + 256);
+                const int xo = ((ks * X_ROWS_PER_KS + dy) * HALO_W + dx) * 16;
+                const bf16x8 bh = tr_frag(xh + xo, xh + xo + X_HALF2);
+                const bf16x8 bl = tr_frag(xl + xo, xl + xo + X_HALF2);
                 acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[tap], 0, 0, 0);
@@ -953,10 +1005,16 @@ template <int COT, int CIT>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision, hipStream_t s) {
     dim3 grid(p.nwx, p.nslices);
     if (precision == 1 && p.tw == 32) {
-        if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0>), grid, dim3(256), 0, s, a);
-        else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2>), grid, dim3(256), 0, s, a);
+        if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32>), grid, dim3(256), 0, s, a);
+        else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1, 32>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2, 32>), grid, dim3(256), 0, s, a);
         return ngan::launch_status("ngan_conv3x3_wgrad(bf16x3)");
+    }
+    if (precision == 1) {
+        if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 16>), grid, dim3(256), 0, s, a);
+        else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1, 16>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2, 16>), grid, dim3(256), 0, s, a);
+        return ngan::launch_status("ngan_conv3x3_wgrad(bf16x3, 16x16 tiles)");
     }
     if (p.tw == 32) {
         if (res == 0) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 0, 32>), grid, dim3(256), 0, s, a);
