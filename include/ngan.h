@@ -70,6 +70,21 @@ int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, flo
                      int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
                      float slope, float eps, int precision, void* stream);
 
+/* The same kernels with two more fused epilogues (what the hand-scheduled first-order passes of train.py:365, 384 use):
+ *   epilogue 2: the call computes an input gradient g (packed = flipped weights) and applies the backward of the
+ *               LeakyReLU -> PixelNorm that produced the layer's input: y = m*(g - aux_in*mean_c(g*aux_in))/aux_rn with
+ *               m = aux_in > 0 ? 1 : slope.  aux_in (same shape as y, also with out_mode 1) is that input, aux_rn its norms.
+ *               No resampling, no bias.  Always available: shapes without a fused kernel run the PixelNorm backward in place
+ *               as a second launch (ngan_conv3x3_epilogue_fused tells which).
+ *   epilogue 3: epilogue 1 followed by ToImage (models.py:141-146, one colour): aux_out (B,H,W) = tanh(sum_c aux_in[c]*y[c]);
+ *               aux_in = the N colour weights.  y / rnorm may be NULL (inference: the activation is never written).
+ *               Only where ngan_conv3x3_epilogue_fused(...) returns 1. */
+int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision);
+int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
+                        const float* aux_in, const float* aux_rn, float* aux_out,
+                        int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                        float slope, float eps, int precision, void* stream);
+
 /* name of the kernel template instance ngan_conv3x3_fwd dispatches to for these arguments, as rocprofv3 prints it
  * (profiling aid: lets bench.py label its HIP-event timings with the same names as the kernel trace) */
 int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision,
@@ -131,6 +146,10 @@ int ngan_to_image_bwd(const float* g, const float* t, const float* x, const floa
  * (h, w) is always the LOW resolution; adjoint = transpose of the linear map. */
 int ngan_up2_fwd(const float* x, float* y, int B, int h, int w, int C, void* stream);
 int ngan_up2_adjoint(const float* gy, float* gx, int B, int h, int w, int C, void* stream);
+/* up2_adjoint followed by the backward of the LeakyReLU -> PixelNorm that produced the low-resolution tensor `yprev` (B,h,w,C) with
+ * norms `rnorm`: out = m*(g' - yprev*mean_c(g'*yprev))/rnorm, g' = up2_adjoint(g).  C/4 a power of two <= 64. */
+int ngan_up2_adjoint_pnbwd(const float* g, const float* yprev, const float* rnorm, float* out, int B, int h, int w, int C,
+                           float slope, void* stream);
 int ngan_pool2_fwd(const float* x, float* y, int B, int h, int w, int C, void* stream);
 int ngan_pool2_adjoint(const float* gy, float* gx, int B, int h, int w, int C, void* stream);
 

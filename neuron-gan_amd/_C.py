@@ -17,6 +17,7 @@ _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_floa
 SIGNATURES = {
     "ngan_conv3x3_pack_weights": [_P, _P, _I, _I, _I, _F, _I, _P],
     "ngan_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
+    "ngan_conv3x3_fwd_ex": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "ngan_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "ngan_lrelu_pixelnorm_fwd": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
     "ngan_lrelu_pixelnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
@@ -29,6 +30,7 @@ SIGNATURES = {
     "ngan_to_image_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "ngan_up2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "ngan_up2_adjoint": [_P, _P, _I, _I, _I, _I, _P],
+    "ngan_up2_adjoint_pnbwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ngan_pool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "ngan_pool2_adjoint": [_P, _P, _I, _I, _I, _I, _P],
     "ngan_lerp": [_P, _P, _P, _P, _L, _P],
@@ -53,6 +55,7 @@ NON_STATUS = {
     "ngan_conv3x3_wgrad_workspace_bytes": ([_I, _I, _I, _I, _I], _Z),
     "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
     "ngan_conv3x3_uses_bf16x3": ([_I, _I, _I, _I, _I, _I, _I], _I),
+    "ngan_conv3x3_epilogue_fused": ([_I, _I, _I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_packed_floats": ([_I, _I, _I], _L),
     "ngan_conv3x3_pack_elements": ([_I, _I, _I, _I], _L),
     "ngan_conv3x3_wgrad_plan": ([_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int)], _I),
@@ -145,6 +148,10 @@ def conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, precision=0
 
 def conv3x3_uses_bf16x3(B, H, W, K, N, resample, precision) -> int:
     return int(lib().ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, precision))
+
+
+def conv3x3_epilogue_fused(B, H, W, K, N, resample, epilogue, out_mode, precision) -> bool:
+    return bool(lib().ngan_conv3x3_epilogue_fused(B, H, W, K, N, resample, epilogue, out_mode, precision))
 
 
 def conv3x3_packed_floats(cout, cin, precision) -> int:

@@ -496,35 +496,80 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             for (int mt = 0; mt < MTW; ++mt) {
                 float4 c = make_float4(acc[pg][mt][0] + bv[mt].x, acc[pg][mt][1] + bv[mt].y,
                                        acc[pg][mt][2] + bv[mt].z, acc[pg][mt][3] + bv[mt].w);
-                if (EPI == 1) {
+                if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE) {
                     c.x = fmaxf(c.x, a.slope * c.x); c.y = fmaxf(c.y, a.slope * c.y);   // LeakyReLU, 0 <= slope <= 1
                     c.z = fmaxf(c.z, a.slope * c.z); c.w = fmaxf(c.w, a.slope * c.w);
                     ss += f4dot(c, c);
                 }
                 v[mt] = c;
             }
-            if (EPI == 1) {
+            if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE) {
                 ss += __shfl_xor(ss, 16, 64);
                 ss += __shfl_xor(ss, 32, 64);
                 const float m = ss * inv_n + a.eps;
                 const float inv = __builtin_amdgcn_rsqf(m);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) v[mt] = f4scale(v[mt], inv);
-                if (valid && q == 0) a.rn[img + (long)gy * a.W + gx] = m * inv;
+                if (valid && q == 0 && (EPI == EPI_LRELU_PN || a.y)) a.rn[img + (long)gy * a.W + gx] = m * inv;
             }
-            if (valid) {
-                if (OUTMODE == 0) {
+            if (EPI == EPI_TO_IMAGE) {
+                float d = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) d += f4dot(v[mt], ld4(a.ay + mt * 16 + q * 4));
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+                if (valid && q == 0) a.aout[img + (long)gy * a.W + gx] = tanhf(d);
+            }
+            if (EPI == EPI_PN_BWD && OUTMODE == 0) {
+                // backward of the LeakyReLU -> PixelNorm that produced this layer's input, applied to the gradient just computed
+                const long pix = img + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
+                float4 yy[MTW];
+                float s = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    yy[mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
+                    s += f4dot(v[mt], yy[mt]);
+                }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                s *= inv_n;
+                const float inv_r = 1.0f / a.arn[pix];
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) v[mt] = pn_bwd4(v[mt], yy[mt], s, inv_r, a.slope);
+            }
+            if (OUTMODE == 0) {
+                if (valid && (EPI != EPI_TO_IMAGE || a.y)) {
                     float* o = a.y + (img + (long)gy * a.W + gx) * N + q * 4;
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt) st4(o + mt * 16, v[mt]);
-                } else {
-                    const long W2 = 2L * a.W;
-                    float* o = a.y + (4 * img + (long)(2 * gy) * W2 + 2 * gx) * N + q * 4;
+                }
+            } else {
+                const long W2 = 2L * a.W;
+                const long o00 = 4 * img + (long)(2 * (valid ? gy : 0)) * W2 + 2 * (valid ? gx : 0);
 #pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) {
-                        float4 s4 = f4scale(v[mt], 0.25f);
-                        st4(o + mt * 16, s4); st4(o + N + mt * 16, s4);
-                        st4(o + W2 * N + mt * 16, s4); st4(o + W2 * N + N + mt * 16, s4);
+                for (int sub = 0; sub < 4; ++sub) {
+                    const long pix = o00 + (sub >> 1) * W2 + (sub & 1);
+                    float4 o4[MTW];
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) o4[mt] = f4scale(v[mt], 0.25f);
+                    if (EPI == EPI_PN_BWD) {
+                        float4 yy[MTW];
+                        float s = 0.f;
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) {
+                            yy[mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
+                            s += f4dot(o4[mt], yy[mt]);
+                        }
+                        s += __shfl_xor(s, 16, 64);
+                        s += __shfl_xor(s, 32, 64);
+                        s *= inv_n;
+                        const float inv_r = 1.0f / a.arn[pix];
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) o4[mt] = pn_bwd4(o4[mt], yy[mt], s, inv_r, a.slope);
+                    }
+                    if (valid) {
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) st4(a.y + pix * N + mt * 16 + q * 4, o4[mt]);
                     }
                 }
             }
@@ -556,6 +601,8 @@ int launch_persist(ConvArgs a, hipStream_t s) {
 
 template <int MTW, int KG, int PREC>
 int dispatch_persist2(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
+    if (epi == EPI_PN_BWD) return outmode == 1 ? launch_persist<MTW, KG, 0, EPI_PN_BWD, 1, PREC>(a, s) : launch_persist<MTW, KG, 0, EPI_PN_BWD, 0, PREC>(a, s);
+    if (epi == EPI_TO_IMAGE) return launch_persist<MTW, KG, 0, EPI_TO_IMAGE, 0, PREC>(a, s);
     if (outmode == 1) return launch_persist<MTW, KG, 0, 0, 1, PREC>(a, s);
     if (res == 0) return epi ? launch_persist<MTW, KG, 0, 1, 0, PREC>(a, s) : launch_persist<MTW, KG, 0, 0, 0, PREC>(a, s);
     return epi ? launch_persist<MTW, KG, 2, 1, 0, PREC>(a, s) : launch_persist<MTW, KG, 2, 0, 0, PREC>(a, s);
@@ -1128,23 +1175,38 @@ extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int
     return ngan::launch_status("ngan_conv3x3_pack_weights");
 }
 
-extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
-                                int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                                float slope, float eps, int precision, void* stream) {
-    NGAN_REQUIRE(x && packed && y, NGAN_ERR_ARG, "conv3x3_fwd: null pointer");
+extern "C" int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision) {
+    if (epilogue == EPI_NONE || epilogue == EPI_LRELU_PN) return 1;
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const bool persist = persist_eligible(B, H, W, K, N, resample);
+    if (epilogue == EPI_TO_IMAGE) return persist && resample == 0 && out_mode == 0 ? 1 : 0;
+    if (epilogue == EPI_PN_BWD) return (persist && resample == 0) || (precision == 1 && resample == 0 && ngan::conv3x3_mid_eligible(B, H, W, K, N)) ? 1 : 0;
+    return 0;
+}
+
+extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
+                                   const float* aux_in, const float* aux_rn, float* aux_out,
+                                   int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                                   float slope, float eps, int precision, void* stream) {
+    NGAN_REQUIRE(x && packed && (y || epilogue == EPI_TO_IMAGE), NGAN_ERR_ARG, "conv3x3_fwd: null pointer");
     NGAN_REQUIRE(precision == 0 || (precision == 1 && ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, 1)), NGAN_ERR_ARG,
                  "conv3x3_fwd: precision %d is not available for this shape (ask ngan_conv3x3_uses_bf16x3)", precision);
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_fwd: bad dims B=%d H=%d W=%d", B, H, W);
     NGAN_REQUIRE(K > 0 && K % 16 == 0, NGAN_ERR_SHAPE, "conv3x3_fwd: K=%d must be a positive multiple of 16", K);
     NGAN_REQUIRE(N == 16 || N == 32 || N == 64 || N == 128, NGAN_ERR_SHAPE, "conv3x3_fwd: N=%d must be 16/32/64/128", N);
     NGAN_REQUIRE(resample >= 0 && resample <= 2, NGAN_ERR_ARG, "conv3x3_fwd: resample %d", resample);
-    NGAN_REQUIRE(epilogue == 0 || epilogue == 1, NGAN_ERR_ARG, "conv3x3_fwd: epilogue %d", epilogue);
-    NGAN_REQUIRE(out_mode == 0 || (out_mode == 1 && epilogue == 0 && resample == 0), NGAN_ERR_ARG,
-                 "conv3x3_fwd: out_mode %d needs epilogue 0 and resample 0", out_mode);
-    NGAN_REQUIRE(epilogue == 0 || rnorm, NGAN_ERR_ARG, "conv3x3_fwd: epilogue 1 needs rnorm");
+    NGAN_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_TO_IMAGE, NGAN_ERR_ARG, "conv3x3_fwd: epilogue %d", epilogue);
+    NGAN_REQUIRE(out_mode == 0 || (out_mode == 1 && (epilogue == EPI_NONE || epilogue == EPI_PN_BWD) && resample == 0), NGAN_ERR_ARG,
+                 "conv3x3_fwd: out_mode %d needs epilogue 0 or 2 and resample 0", out_mode);
+    NGAN_REQUIRE(epilogue != EPI_LRELU_PN || rnorm, NGAN_ERR_ARG, "conv3x3_fwd: epilogue 1 needs rnorm");
+    NGAN_REQUIRE(epilogue != EPI_PN_BWD || (aux_in && aux_rn && resample == 0 && !bias), NGAN_ERR_ARG,
+                 "conv3x3_fwd: epilogue 2 needs aux_in / aux_rn, no resampling and no bias");
+    NGAN_REQUIRE(epilogue != EPI_TO_IMAGE || (aux_in && aux_out && (!y || rnorm) &&
+                                              ngan_conv3x3_epilogue_fused(B, H, W, K, N, resample, epilogue, out_mode, precision)),
+                 NGAN_ERR_ARG, "conv3x3_fwd: epilogue 3 needs aux_in (colour weights), aux_out and a shape ngan_conv3x3_epilogue_fused accepts");
     NGAN_REQUIRE(resample != NGAN_RESAMPLE_UP2 || (H % 2 == 0 && W % 2 == 0), NGAN_ERR_SHAPE,
                  "conv3x3_fwd: bilinear x2 needs even H, W");
-    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, 0, 0, slope, eps};
+    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, 0, 0, slope, eps, aux_in, aux_rn, aux_out};
     hipStream_t s = (hipStream_t)stream;
     if (persist_eligible(B, H, W, K, N, resample)) {
         // large image, few channels: persistent pipelined kernel
@@ -1154,13 +1216,26 @@ extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float
                        : dispatch_persist<2, 2>(a, resample, epilogue, out_mode, precision, s);
     }
     if (precision == 1)   // many channels, small image: split-bf16 kernel of conv3x3_mid.hip
-        return ngan::conv3x3_mid_launch(x, packed, bias, y, rnorm, B, H, W, K, N, resample, epilogue, out_mode, slope, eps, s);
+        return ngan::conv3x3_mid_launch(x, packed, bias, y, rnorm, aux_in, aux_rn, B, H, W, K, N, resample, epilogue, out_mode, slope, eps, s);
+    // generic exact-fp32 kernel: it has epilogues 0 and 1; the PixelNorm backward runs as a second launch, in place
+    const int epi = epilogue == EPI_PN_BWD ? EPI_NONE : epilogue;
+    int st;
     switch (N / 16) {
-        case 1: return dispatch_conv<0>(a, resample, epilogue, out_mode, s);
-        case 2: return dispatch_conv<1>(a, resample, epilogue, out_mode, s);
-        case 4: return dispatch_conv<2>(a, resample, epilogue, out_mode, s);
-        default: return dispatch_conv<3>(a, resample, epilogue, out_mode, s);
+        case 1: st = dispatch_conv<0>(a, resample, epi, out_mode, s); break;
+        case 2: st = dispatch_conv<1>(a, resample, epi, out_mode, s); break;
+        case 4: st = dispatch_conv<2>(a, resample, epi, out_mode, s); break;
+        default: st = dispatch_conv<3>(a, resample, epi, out_mode, s); break;
     }
+    if (st || epilogue != EPI_PN_BWD) return st;
+    return ngan_lrelu_pixelnorm_bwd(y, nullptr, aux_in, aux_rn, y, (long)B * H * W * (out_mode ? 4 : 1), N, slope, stream);
+}
+
+extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
+                                int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                                float slope, float eps, int precision, void* stream) {
+    NGAN_REQUIRE(epilogue == 0 || epilogue == 1, NGAN_ERR_ARG, "conv3x3_fwd: epilogue %d (2 and 3 need ngan_conv3x3_fwd_ex)", epilogue);
+    return ngan_conv3x3_fwd_ex(x, packed, bias, y, rnorm, nullptr, nullptr, nullptr, B, H, W, K, N, resample, epilogue, out_mode,
+                               slope, eps, precision, stream);
 }
 
 extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,

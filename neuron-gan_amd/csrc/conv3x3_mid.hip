@@ -60,7 +60,7 @@ template <int KG, int PGW, int MTW, int WN, int EPI, int OUTMODE>
 __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resample) {
     using C = MidCfg<KG, PGW, MTW, WN>;
     constexpr int K = C::K, PITCH = C::PITCH, NPIX = C::NPIX, NSTEP = C::NSTEP, D = C::D;
-    constexpr int SS_BYTES = (EPI == 1 && WN > 1) ? WN * 4 * 16 * 4 : 0;
+    constexpr int SS_BYTES = (EPI != EPI_NONE && WN > 1) ? WN * 4 * 16 * 4 : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NPIX * PITCH + SS_BYTES];
     float* ss_l = reinterpret_cast<float*>(smem + NPIX * PITCH);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,69 +168,138 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) bv[mt] = a.bias ? ld4(a.bias + (mt0 + mt) * 16 + q * 4) : f4zero();
     float4 v[PGW][MTW];
-    float ssum[PGW];
 #pragma unroll
-    for (int pg = 0; pg < PGW; ++pg) {
-        float ss = 0.f;
+    for (int pg = 0; pg < PGW; ++pg)
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-            float4 c = make_float4(acc[pg][mt][0] + bv[mt].x, acc[pg][mt][1] + bv[mt].y,
-                                   acc[pg][mt][2] + bv[mt].z, acc[pg][mt][3] + bv[mt].w);
-            if (EPI == 1) {
-                c.x = c.x > 0.f ? c.x : a.slope * c.x; c.y = c.y > 0.f ? c.y : a.slope * c.y;
-                c.z = c.z > 0.f ? c.z : a.slope * c.z; c.w = c.w > 0.f ? c.w : a.slope * c.w;
-                ss += f4dot(c, c);
+        for (int mt = 0; mt < MTW; ++mt)
+            v[pg][mt] = make_float4(acc[pg][mt][0] + bv[mt].x, acc[pg][mt][1] + bv[mt].y, acc[pg][mt][2] + bv[mt].z, acc[pg][mt][3] + bv[mt].w);
+    // sum over ALL channels of a pixel of a per-lane partial: 4 q-lanes by shuffles, the WN waves through LDS (every thread calls it)
+    auto pixel_sum = [&](float (&part)[PGW]) {
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg) {
+            part[pg] += __shfl_xor(part[pg], 16, 64);
+            part[pg] += __shfl_xor(part[pg], 32, 64);
+        }
+        if (WN > 1) {
+            __syncthreads();           // ss_l may still be read from a previous call
+            if (q == 0) {
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) ss_l[(wn * 4 + wp * PGW + pg) * 16 + p] = part[pg];
             }
-            v[pg][mt] = c;
-        }
-        if (EPI == 1) {
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-        }
-        ssum[pg] = ss;
-    }
-    if (EPI == 1 && WN > 1) {
-        if (q == 0) {
+            __syncthreads();
 #pragma unroll
-            for (int pg = 0; pg < PGW; ++pg) ss_l[(wn * 4 + wp * PGW + pg) * 16 + p] = ssum[pg];
+            for (int pg = 0; pg < PGW; ++pg) {
+                float t = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WN; ++w2) t += ss_l[(w2 * 4 + wp * PGW + pg) * 16 + p];
+                part[pg] = t;
+            }
         }
-        __syncthreads();
+    };
+    const float inv_n = 1.0f / (float)a.N;
+    if (EPI == EPI_LRELU_PN) {
+        float ssum[PGW];
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg) {
             float ss = 0.f;
 #pragma unroll
-            for (int w2 = 0; w2 < WN; ++w2) ss += ss_l[(w2 * 4 + wp * PGW + pg) * 16 + p];
+            for (int mt = 0; mt < MTW; ++mt) {
+                float4 c = v[pg][mt];
+                c.x = c.x > 0.f ? c.x : a.slope * c.x; c.y = c.y > 0.f ? c.y : a.slope * c.y;
+                c.z = c.z > 0.f ? c.z : a.slope * c.z; c.w = c.w > 0.f ? c.w : a.slope * c.w;
+                ss += f4dot(c, c);
+                v[pg][mt] = c;
+            }
             ssum[pg] = ss;
         }
-    }
-    const float inv_n = 1.0f / (float)a.N;
+        pixel_sum(ssum);
 #pragma unroll
-    for (int pg = 0; pg < PGW; ++pg) {
-        const int gy = y0 + wp * PGW + pg, gx = x0 + p;
-        const bool valid = gy < a.H && gx < a.W;
-        if (EPI == 1) {
+        for (int pg = 0; pg < PGW; ++pg) {
+            const int gy = y0 + wp * PGW + pg, gx = x0 + p;
             const float r = sqrtf(ssum[pg] * inv_n + a.eps);
             const float inv = 1.0f / r;
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) v[pg][mt] = f4scale(v[pg][mt], inv);
-            if (valid && q == 0 && wn == 0) a.rn[((long)b * a.H + gy) * a.W + gx] = r;
+            if (gy < a.H && gx < a.W && q == 0 && wn == 0) a.rn[((long)b * a.H + gy) * a.W + gx] = r;
         }
-        if (valid) {
-            const int ch0 = mt0 * 16 + q * 4;
-            if (OUTMODE == 0) {
-                float* o = a.y + (((long)b * a.H + gy) * a.W + gx) * a.N + ch0;
+    }
+    const int ch0 = mt0 * 16 + q * 4;
+    if (OUTMODE == 0) {
+        long pix[PGW];
+        bool valid[PGW];
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) st4(o + mt * 16, v[pg][mt]);
-            } else {
-                const long W2 = 2L * a.W;
-                float* o = a.y + (((long)b * 2 * a.H + 2 * gy) * W2 + 2 * gx) * a.N + ch0;
+        for (int pg = 0; pg < PGW; ++pg) {
+            const int gy = y0 + wp * PGW + pg, gx = x0 + p;
+            valid[pg] = gy < a.H && gx < a.W;
+            pix[pg] = ((long)b * a.H + (valid[pg] ? gy : 0)) * a.W + (valid[pg] ? gx : 0);
+        }
+        if (EPI == EPI_PN_BWD) {
+            float4 yy[PGW][MTW];
+            float s[PGW];
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) {
+                s[pg] = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
-                    const float4 s4 = f4scale(v[pg][mt], 0.25f);
-                    st4(o + mt * 16, s4); st4(o + a.N + mt * 16, s4);
-                    st4(o + W2 * a.N + mt * 16, s4); st4(o + W2 * a.N + a.N + mt * 16, s4);
+                    yy[pg][mt] = ld4(a.ay + pix[pg] * a.N + ch0 + mt * 16);
+                    s[pg] += f4dot(v[pg][mt], yy[pg][mt]);
                 }
             }
+            pixel_sum(s);
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) {
+                const float inv_r = 1.0f / a.arn[pix[pg]];
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) v[pg][mt] = pn_bwd4(v[pg][mt], yy[pg][mt], s[pg] * inv_n, inv_r, a.slope);
+            }
+        }
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg)
+            if (valid[pg]) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) st4(a.y + pix[pg] * a.N + ch0 + mt * 16, v[pg][mt]);
+            }
+    } else {
+        const long W2 = 2L * a.W;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            long pix[PGW];
+            bool valid[PGW];
+            float4 o4[PGW][MTW];
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) {
+                const int gy = y0 + wp * PGW + pg, gx = x0 + p;
+                valid[pg] = gy < a.H && gx < a.W;
+                pix[pg] = ((long)b * 2 * a.H + 2 * (valid[pg] ? gy : 0) + (sub >> 1)) * W2 + 2 * (valid[pg] ? gx : 0) + (sub & 1);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) o4[pg][mt] = f4scale(v[pg][mt], 0.25f);
+            }
+            if (EPI == EPI_PN_BWD) {
+                float4 yy[PGW][MTW];
+                float s[PGW];
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) {
+                    s[pg] = 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        yy[pg][mt] = ld4(a.ay + pix[pg] * a.N + ch0 + mt * 16);
+                        s[pg] += f4dot(o4[pg][mt], yy[pg][mt]);
+                    }
+                }
+                pixel_sum(s);
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) {
+                    const float inv_r = 1.0f / a.arn[pix[pg]];
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) o4[pg][mt] = pn_bwd4(o4[pg][mt], yy[pg][mt], s[pg] * inv_n, inv_r, a.slope);
+                }
+            }
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg)
+                if (valid[pg]) {
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) st4(a.y + pix[pg] * a.N + ch0 + mt * 16, o4[pg][mt]);
+                }
         }
     }
 }
@@ -249,7 +318,9 @@ int mid_slice(int n_tiles, int N) {
 template <int KG, int PGW, int MTW, int WN>
 int mid_launch_cfg(ConvArgs a, int n_tiles, int n_slices, int resample, int epi, int outmode, hipStream_t s) {
     const dim3 grid(n_tiles, n_slices), block(256);
-    if (outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 1>), grid, block, 0, s, a, resample);
+    if (epi == EPI_PN_BWD && outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 1>), grid, block, 0, s, a, resample);
+    else if (epi == EPI_PN_BWD) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 0>), grid, block, 0, s, a, resample);
+    else if (outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 1>), grid, block, 0, s, a, resample);
     else if (epi) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 1, 0>), grid, block, 0, s, a, resample);
     else hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 0>), grid, block, 0, s, a, resample);
     return ngan::launch_status("ngan_conv3x3_fwd(mid)");
@@ -271,26 +342,29 @@ bool conv3x3_mid_eligible(int B, int H, int W, int K, int N) {
     return B > 0 && H > 0 && W > 0 && (K == 32 || K == 64 || K == 128) && (N == 32 || N == 64 || N == 128);
 }
 
-int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, int B, int H, int W,
-                       int K, int N, int resample, int epilogue, int out_mode, float slope, float eps, hipStream_t s) {
-    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, ceil_div(W, 16), ceil_div(H, 4), slope, eps};
+int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, const float* aux_in,
+                       const float* aux_rn, int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                       float slope, float eps, hipStream_t s) {
+    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, ceil_div(W, 16), ceil_div(H, 4), slope, eps, aux_in, aux_rn, nullptr};
     const int n_tiles = B * a.tiles_x * a.tiles_y;
     const int ns = mid_slice(n_tiles, N);
-    const bool fused = epilogue == 0 || ns == N;
-    const int epi = fused ? epilogue : 0;
+    const bool fused = epilogue == EPI_NONE || ns == N;      // the channel-reducing epilogues need all N channels in one workgroup
+    const int epi = fused ? epilogue : EPI_NONE;
     int st;
     if (K == 32) st = mid_launch_kg<1>(a, n_tiles, ns, resample, epi, out_mode, s);
     else if (K == 64) st = mid_launch_kg<2>(a, n_tiles, ns, resample, epi, out_mode, s);
     else st = mid_launch_kg<4>(a, n_tiles, ns, resample, epi, out_mode, s);
     if (st || fused) return st;
-    // channels were split over workgroups: LeakyReLU -> PixelNorm over all N channels of a pixel, in place (bias already added)
-    return ngan_lrelu_pixelnorm_fwd(y, nullptr, y, rnorm, (long)B * H * W, N, slope, eps, (void*)s);
+    // channels were split over workgroups: the epilogue runs as a second, tiny launch over all N channels of a pixel, in place
+    const long npix = (long)B * H * W * (out_mode ? 4 : 1);
+    if (epilogue == EPI_LRELU_PN) return ngan_lrelu_pixelnorm_fwd(y, nullptr, y, rnorm, npix, N, slope, eps, (void*)s);   // bias already added
+    return ngan_lrelu_pixelnorm_bwd(y, nullptr, aux_in, aux_rn, y, npix, N, slope, (void*)s);
 }
 
 int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, char* buf, int len) {
     const int n_tiles = B * ceil_div(W, 16) * ceil_div(H, 4);
     const int ns = mid_slice(n_tiles, N);
-    const int epi = (epilogue && ns == N && !out_mode) ? 1 : 0;
+    const int epi = ns == N ? epilogue : 0;
     const int pgw = ns == 128 ? 4 : 2, mtw = ns == 32 ? 1 : 2, wnn = ns == 128 ? 4 : 2;
     snprintf(buf, len, "conv3x3_mid_kernel<%d, %d, %d, %d, %d, %d>", K / 32, pgw, mtw, wnn, epi, out_mode ? 1 : 0);
     return NGAN_OK;

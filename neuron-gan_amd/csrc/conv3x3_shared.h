@@ -7,11 +7,27 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// Epilogues of the forward / input-gradient kernels (template parameter EPI):
+//   0  y = conv + bias
+//   1  y = PixelNorm(LeakyReLU(conv + bias)), rn = the per-pixel norm
+//   2  the kernel computes an INPUT GRADIENT g (of the next layer); its epilogue applies the backward of the LeakyReLU -> PixelNorm
+//      that produced this layer's input:  y = m * (g - ay * mean_c(g * ay)) / arn,  m = ay > 0 ? 1 : slope
+//      (ay = that input, i.e. the previous layer's output, arn its norms; same shape as y, also for the pool-adjoint store)
+//   3  epilogue 1 followed by ToImage: aout[pixel] = tanh(sum_c ay[c] * y[c])  (ay = the 1x1 colour weights, one colour);
+//      y and rn are stored only if y != nullptr
+enum { EPI_NONE = 0, EPI_LRELU_PN = 1, EPI_PN_BWD = 2, EPI_TO_IMAGE = 3 };
+
 struct ConvArgs {
     const float* x; const float* wp; const float* bias; float* y; float* rn;
     int B, H, W, K, N, tiles_x, tiles_y;
     float slope, eps;
+    const float* ay; const float* arn; float* aout;
 };
+
+__device__ __forceinline__ float4 pn_bwd4(float4 g, float4 yy, float s, float inv_r, float slope) {
+    return make_float4((g.x - yy.x * s) * inv_r * (yy.x > 0.f ? 1.f : slope), (g.y - yy.y * s) * inv_r * (yy.y > 0.f ? 1.f : slope),
+                       (g.z - yy.z * s) * inv_r * (yy.z > 0.f ? 1.f : slope), (g.w - yy.w * s) * inv_r * (yy.w > 0.f ? 1.f : slope));
+}
 
 // 4 consecutive channels (starting at ch) of conv-input pixel (gy, gx) of image b, after resampling.
 // C = channel count of x.  Out-of-image pixels are the conv's zero padding.
@@ -44,7 +60,8 @@ __device__ __forceinline__ float4 load_resampled(const float* __restrict__ x, in
 // conv3x3_mid.hip: split-bf16 kernel for many-channel layers on small images (K, N multiples of 32, up to 128)
 namespace ngan {
 bool conv3x3_mid_eligible(int B, int H, int W, int K, int N);
-int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, int B, int H, int W,
-                       int K, int N, int resample, int epilogue, int out_mode, float slope, float eps, hipStream_t s);
+int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, const float* aux_in,
+                       const float* aux_rn, int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                       float slope, float eps, hipStream_t s);
 int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, char* buf, int len);
 }  // namespace ngan

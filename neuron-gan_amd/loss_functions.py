@@ -38,7 +38,8 @@ class D_W_loss(nn.Module):
                 fake_images = self.generator_net(z)
         # D(real) and D(fake) share the weights and no op couples samples, so they run as ONE critic pass over the
         # concatenated batch (the reference makes two calls, loss_functions.py:21, 29; per-sample results are identical)
-        scores = self.discriminator_net(torch.cat([real_images, fake_images], dim=0))
+        with ops.first_order_only():      # differentiated once (train.py:365): fused PixelNorm-backward epilogues apply
+            scores = self.discriminator_net(torch.cat([real_images, fake_images], dim=0))
         real_images_score = scores[:batch_size]
         score_real = real_images_score.mean()
         score_fake = scores[batch_size:].mean()
@@ -64,7 +65,8 @@ class G_W_loss(nn.Module):
         batch_size, device = real_images_batch.size(0), real_images_batch.device
         z_latent = _latents(self.generator_net, batch_size, device, z)
         fake_images = self.generator_net(z_latent)
-        G_loss = -self.discriminator_net(fake_images).mean()
+        with ops.first_order_only():      # differentiated once (train.py:384)
+            G_loss = -self.discriminator_net(fake_images).mean()
         if self.check_nan and torch.isnan(G_loss):
             raise ValueError('Generator loss is nan.')
         return G_loss, z_latent

@@ -245,12 +245,21 @@ def _resample_of(m):
     return None
 
 
-def run_layers(seq, x):
-    """Evaluate an nn.Sequential of PG building blocks on a channels-last tensor (or on latents for the stem),
-    fusing  [resample] conv LeakyReLU PixelNorm  groups into single kernels."""
-    mods = list(seq)
+def _plan(mods, steps=None, pending=None):
+    """Flatten an nn.Sequential of PG building blocks (nested Conv2d_scale_blocks included) into execution steps, merging
+    [resample] conv LeakyReLU PixelNorm  groups:  ('stem', linear, size, slope) | ('conv_lrelu_pn', conv, resample, slope) |
+    ('conv', conv, resample) | ('lrelu_pn', slope) | ('resample', code) | ('flatten',)"""
+    top = steps is None
+    if top:
+        steps, pending = [], [ops.RES_NONE]
+    mods = list(mods)
     i, n = 0, len(mods)
-    pending = ops.RES_NONE
+
+    def flush():
+        if pending[0] != ops.RES_NONE:
+            steps.append(('resample', pending[0]))
+            pending[0] = ops.RES_NONE
+
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
@@ -258,49 +267,102 @@ def run_layers(seq, x):
         nxt3 = mods[i + 3] if i + 3 < n else None
         res = _resample_of(m)
         if isinstance(m, Conv2d_scale_block):
-            if pending != ops.RES_NONE:
-                x = _apply_resample(x, pending)
-                pending = ops.RES_NONE
-            x = run_layers(m, x)
+            flush()
+            _plan(m, steps, pending)
+            flush()
             i += 1
         elif res is not None:
-            if pending != ops.RES_NONE:
-                x = _apply_resample(x, pending)
-            pending = res
+            flush()
+            pending[0] = res
             i += 1
         elif (isinstance(m, Linear_normalized) and isinstance(nxt, nn.Unflatten) and isinstance(nxt2, nn.LeakyReLU)
               and isinstance(nxt3, PixelNorm)):
             c, s, s2 = nxt.unflattened_size
             if s != s2 or m.bias is not None:
                 raise NotImplementedError('generator stem must be square and bias-free')
-            x, _ = ops.LinearLReLUPN.apply(x, m.weight, s, m.scale_value, nxt2.negative_slope)
+            steps.append(('stem', m, s, nxt2.negative_slope))
             i += 4
         elif isinstance(m, Conv2d_normalized) and m.is_3x3() and isinstance(nxt, nn.LeakyReLU) and isinstance(nxt2, PixelNorm):
-            x, _ = ops.ConvLReLUPN.apply(x, m.weight, m.bias, pending, m.scale_value, nxt.negative_slope)
-            pending = ops.RES_NONE
+            steps.append(('conv_lrelu_pn', m, pending[0], nxt.negative_slope))
+            pending[0] = ops.RES_NONE
             i += 3
         elif isinstance(m, Conv2d_normalized):
-            x = m.nhwc(x, pending) if m.is_3x3() else m.nhwc(_apply_resample(x, pending))
-            pending = ops.RES_NONE
+            if m.is_3x3():
+                steps.append(('conv', m, pending[0]))
+                pending[0] = ops.RES_NONE
+            else:
+                flush()
+                steps.append(('conv', m, ops.RES_NONE))
             i += 1
         elif isinstance(m, nn.LeakyReLU) and isinstance(nxt, PixelNorm):
-            x = _apply_resample(x, pending)
-            pending = ops.RES_NONE
-            x, _ = ops.LReLUPN.apply(x, None, m.negative_slope)
+            flush()
+            steps.append(('lrelu_pn', m.negative_slope))
             i += 2
         elif isinstance(m, PixelNorm):
-            x = _apply_resample(x, pending)
-            pending = ops.RES_NONE
-            x, _ = ops.LReLUPN.apply(x, None, 1.0)
+            flush()
+            steps.append(('lrelu_pn', 1.0))
             i += 1
         elif isinstance(m, nn.Flatten):
-            x = _apply_resample(x, pending)
-            pending = ops.RES_NONE
-            x = x.reshape(x.shape[0], -1)
+            flush()
+            steps.append(('flatten',))
             i += 1
         else:
             raise NotImplementedError(f'no HIP kernel for layer {type(m).__name__} at position {i}')
-    return _apply_resample(x, pending)
+    if top:
+        flush()
+    return steps
+
+
+def _exec(steps, x, link=None, to_image=None):
+    """Run planned steps on a channels-last tensor (or on latents for the stem).  `link`: PNLink of the LeakyReLU->PixelNorm that
+    produced x, if x has no other consumer.  Returns (output, link of the output).  Inside `ops.first_order_only()` consecutive
+    LeakyReLU->PixelNorm producers and conv consumers are linked (ops.PNLink).  `to_image`: a ToImage module applied to the result;
+    where the last step is a fused conv and the shape allows it, conv + ToImage run as one kernel (ops.ConvLReLUPNToImage)."""
+    linking = ops.first_order_enabled() and torch.is_grad_enabled()
+    last = len(steps) - 1
+    for idx, st in enumerate(steps):
+        kind = st[0]
+        if kind == 'conv_lrelu_pn':
+            _, m, res, slope = st
+            if (idx == last and to_image is not None and ops.first_order_enabled()
+                    and ops.to_image_fusable(x, m.weight, to_image.layers[0].weight, res)):
+                t = ops.ConvLReLUPNToImage.apply(x, m.weight, m.bias, to_image.layers[0].weight, res, m.scale_value, slope, link)
+                return t, None
+            out_link = ops.PNLink() if linking else None
+            if link is not None or out_link is not None:
+                x, _ = ops.ConvLReLUPN.apply(x, m.weight, m.bias, res, m.scale_value, slope, link, out_link)
+            else:
+                x, _ = ops.ConvLReLUPN.apply(x, m.weight, m.bias, res, m.scale_value, slope)
+            link = out_link
+        elif kind == 'stem':
+            _, m, size, slope = st
+            out_link = ops.PNLink() if linking else None
+            if out_link is not None:
+                x, _ = ops.LinearLReLUPN.apply(x, m.weight, size, m.scale_value, slope, out_link)
+            else:
+                x, _ = ops.LinearLReLUPN.apply(x, m.weight, size, m.scale_value, slope)
+            link = out_link
+        else:
+            link = None           # every other operator consumes the gradient w.r.t. its input as it is
+            if kind == 'conv':
+                x = st[1].nhwc(x, st[2])
+            elif kind == 'lrelu_pn':
+                x, _ = ops.LReLUPN.apply(x, None, st[1])
+            elif kind == 'resample':
+                x = _apply_resample(x, st[1])
+            elif kind == 'flatten':
+                x = x.reshape(x.shape[0], -1)
+            else:
+                raise AssertionError(kind)
+    if to_image is not None:
+        return to_image.nhwc(x), None
+    return x, link
+
+
+def run_layers(seq, x):
+    """Evaluate an nn.Sequential of PG building blocks on a channels-last tensor (or on latents for the stem),
+    fusing  [resample] conv LeakyReLU PixelNorm  groups into single kernels."""
+    return _exec(_plan(seq), x)[0]
 
 
 def _apply_resample(x, code):
@@ -439,13 +501,15 @@ class Generator_PG(_ProgressiveNet):
         self._tag_parameters()
 
     def forward(self, x):
-        h = run_layers(self.layers, x)
-        if self.alpha_value() < 1:
-            im_start = ops.Up2.apply(self.ToIm.nhwc(h))
-            im_end = self.ToIm_list[0].nhwc(self.conv_block_list[0].nhwc(h))
-            out = ops.Lerp.apply(im_start, im_end, self.alpha.reshape(1))
-        else:
-            out = self.ToIm.nhwc(h)
+        # the generator is only ever differentiated once (train.py:384): its conv chain always runs in first-order mode
+        with ops.first_order_only():
+            if self.alpha_value() < 1:
+                h, _ = _exec(_plan(self.layers), x)          # h has two consumers: no PixelNorm hand-off across it
+                im_start = ops.Up2.apply(self.ToIm.nhwc(h))
+                im_end, _ = _exec(_plan(self.conv_block_list[0]), h, None, to_image=self.ToIm_list[0])
+                out = ops.Lerp.apply(im_start, im_end, self.alpha.reshape(1))
+            else:
+                out, _ = _exec(_plan(self.layers), x, None, to_image=self.ToIm)
         return to_nchw(out)
 
     def _merge_pending_block(self):
@@ -520,23 +584,23 @@ class Discriminator_PG(_ProgressiveNet):
         x = to_nhwc(x)
         if self.alpha_value() < 1:
             y_start = self.FromIm.nhwc(x, pool=True)           # FromIm(downsample(x)), pooled on load
-            y_end = self._from_image_then_block(self.FromIm_list[-1], self.conv_block_list[-1], x)
+            y_end, _ = self._from_image_then_block(self.FromIm_list[-1], self.conv_block_list[-1], x)
             y = ops.Lerp.apply(y_start, y_end, self.alpha.reshape(1))
-            return run_layers(self.layers, y)
+            return _exec(_plan(self.layers), y)[0]
         first = self.layers[0]
         if isinstance(first, Conv2d_scale_block):
-            y = self._from_image_then_block(self.FromIm, first, x)
-            return run_layers(list(self.layers)[1:], y)
-        return run_layers(self.layers, self.FromIm.nhwc(x))
+            y, link = self._from_image_then_block(self.FromIm, first, x)
+            return _exec(_plan(list(self.layers)[1:]), y, link)[0]
+        return _exec(_plan(self.layers), self.FromIm.nhwc(x))[0]
 
     @staticmethod
     def _from_image_then_block(from_im, block, x):
-        """block(FromImage(x)) for a down-sampling block.  FromImage is affine per pixel and AvgPool2d is linear, so
-        pool(FromImage(x)) == FromImage(pool(x)): the image is pooled while FromImage loads it and the block's first
+        """block(FromImage(x)) for a down-sampling block -> (output, its PNLink).  FromImage is affine per pixel and AvgPool2d is
+        linear, so pool(FromImage(x)) == FromImage(pool(x)): the image is pooled while FromImage loads it and the block's first
         conv runs without resampling -- the C-channel tensor at the image's full resolution is never written."""
         if _resample_of(block[0]) == ops.RES_POOL2:
-            return run_layers(list(block)[1:], from_im.nhwc(x, pool=True))
-        return block.nhwc(from_im.nhwc(x))
+            return _exec(_plan(list(block)[1:]), from_im.nhwc(x, pool=True))
+        return _exec(_plan(block), from_im.nhwc(x))
 
     def _merge_pending_block(self):
         self.layers.insert(0, self.conv_block_list.pop(-1))

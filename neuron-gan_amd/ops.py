@@ -23,6 +23,49 @@ from . import _C
 import os
 
 RES_NONE, RES_POOL2, RES_UP2 = 0, 1, 2
+EPI_NONE, EPI_LRELU_PN, EPI_PN_BWD, EPI_TO_IMAGE = 0, 1, 2, 3      # epilogues of ngan_conv3x3_fwd_ex (include/ngan.h)
+
+# ---------------------------------------------------------------------------------------------------------
+# First-order passes.  D(real), D(fake), D(G(z)) and G(z) are differentiated once (train.py:365, 384); only D(x_hat) of the
+# gradient penalty needs the double-backward closure below.  Inside `first_order_only()` the model planner (models._exec) links
+# each LeakyReLU->PixelNorm producer to the ONE conv that consumes its output (`PNLink`), and a plain (not create_graph) backward
+# then lets the consumer's input-gradient kernel apply the producer's LeakyReLU->PixelNorm backward in its epilogue: the gradient
+# w.r.t. the producer's output is never written and re-read, and the producer's own PixelNorm-backward launch disappears.
+# ---------------------------------------------------------------------------------------------------------
+_first_order = 0
+_first_order_allowed = os.environ.get("NGAN_FIRST_ORDER_FUSION", "1") != "0"     # A/B switch for measurements and tests
+
+
+def allow_first_order_fusion(flag):
+    global _first_order_allowed
+    _first_order_allowed = bool(flag)
+
+
+class first_order_only:
+    def __enter__(self):
+        global _first_order
+        _first_order += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _first_order
+        _first_order -= 1
+        return False
+
+
+def first_order_enabled():
+    return _first_order > 0 and _first_order_allowed
+
+
+class PNLink:
+    """Hand-off between the LeakyReLU->PixelNorm that produced a tensor (y, rn) and the single conv consuming it.  The consumer's
+    backward sets `fused` after it has applied the producer's LeakyReLU->PixelNorm backward to the gradient it returns."""
+    __slots__ = ("y", "rn", "slope", "fused")
+
+    def __init__(self):
+        self.y = self.rn = None
+        self.slope = 0.0
+        self.fused = False
 # arithmetic of the 3x3 convolutions: "f32" = exact fp32 MFMA everywhere; "bf16x3" = few-channel layers on large images
 # use the split-bf16 kernels (3 bf16 MFMAs per product group, fp32 accumulate, ~1e-5 relative error), the rest stays fp32
 PRECISIONS = {"f32": 0, "bf16x3": 1}
@@ -166,25 +209,39 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope):
     return y, rn
 
 
-def _run_dgrad(g, weight, resample, scale):
-    """gx = resample^T(conv3x3_transposed(g, scale*W))"""
+def _run_dgrad(g, weight, resample, scale, link=None):
+    """gx = resample^T(conv3x3_transposed(g, scale*W)); with `link`: followed by the backward of the LeakyReLU->PixelNorm that
+    produced the conv's input (link.y, link.rn), fused into the kernel's epilogue where one exists"""
     b, h, w, cout = g.shape
     cin = weight.shape[1]
     if cout != weight.shape[0]:
         raise RuntimeError(f"conv3x3 dgrad: gradient has {cout} channels, weight has {weight.shape[0]} outputs")
     prec = _C.conv3x3_uses_bf16x3(b, h, w, cout, cin, 0, _conv_precision)
     packed = _packed(weight, 1, scale, prec)
+    epi = EPI_PN_BWD if link is not None else EPI_NONE
+    ay, arn, slope = (link.y, link.rn, float(link.slope)) if link is not None else (None, None, 0.0)
     if resample == RES_POOL2:
         gx = torch.empty((b, 2 * h, 2 * w, cin), device=g.device, dtype=torch.float32)
-        _C.call("ngan_conv3x3_fwd", g, packed, None, gx, None, b, h, w, cout, cin, 0, 0, 1, 0.0, 0.0, prec)
+        if link is not None and tuple(ay.shape) != tuple(gx.shape):
+            raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(gx.shape)}")
+        _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gx, None, ay, arn, None, b, h, w, cout, cin, 0, epi, 1, slope, 0.0, prec)
         return gx
-    gfull = torch.empty((b, h, w, cin), device=g.device, dtype=torch.float32)
-    _C.call("ngan_conv3x3_fwd", g, packed, None, gfull, None, b, h, w, cout, cin, 0, 0, 0, 0.0, 0.0, prec)
     if resample == RES_UP2:
+        gfull = torch.empty((b, h, w, cin), device=g.device, dtype=torch.float32)
+        _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gfull, None, None, None, None, b, h, w, cout, cin, 0, EPI_NONE, 0, 0.0, 0.0, prec)
         gx = torch.empty((b, h // 2, w // 2, cin), device=g.device, dtype=torch.float32)
-        _C.call("ngan_up2_adjoint", gfull, gx, b, h // 2, w // 2, cin)
+        if link is not None:
+            if tuple(ay.shape) != tuple(gx.shape):
+                raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(gx.shape)}")
+            _C.call("ngan_up2_adjoint_pnbwd", gfull, ay, arn, gx, b, h // 2, w // 2, cin, slope)
+        else:
+            _C.call("ngan_up2_adjoint", gfull, gx, b, h // 2, w // 2, cin)
         return gx
-    return gfull
+    gx = torch.empty((b, h, w, cin), device=g.device, dtype=torch.float32)
+    if link is not None and tuple(ay.shape) != tuple(gx.shape):
+        raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(gx.shape)}")
+    _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gx, None, ay, arn, None, b, h, w, cout, cin, 0, epi, 0, slope, 0.0, prec)
+    return gx
 
 
 # ---- deferred slab reduction: inside `deferred_wgrad()` the in-place weight gradients only write their slabs; leaving the
@@ -263,37 +320,117 @@ def _channel_sum(g):
 # ---------------------------------------------------------------------------------------------------------
 # 3x3 convolution family
 # ---------------------------------------------------------------------------------------------------------
+def _conv_backward_tail(ctx, x, weight, gc, resample, scale, in_link, has_bias, bias_index=2):
+    """input / weight / bias gradients of a conv given the gradient gc w.r.t. its pre-activation (shared by the fused forms)"""
+    gx = None
+    if ctx.needs_input_grad[0]:
+        if in_link is not None and not torch.is_grad_enabled():
+            gx = _run_dgrad(_c(gc), weight, resample, scale, link=in_link)      # returns d/d(pre-activation of the PRODUCER)
+            in_link.fused = True
+        else:
+            if in_link is not None:
+                in_link.fused = False        # (a create_graph pass after a plain one on a retained graph)
+            gx = ConvDgrad.apply(gc, weight, resample, scale)
+    gw = None
+    if ctx.needs_input_grad[1]:
+        if _accumulates_in_place(weight):
+            _run_wgrad(x, _c(gc), resample, scale, accumulate_into=weight.grad)   # weight.grad += ..., returns None to autograd
+        else:
+            gw = ConvWgrad.apply(x, gc, resample, scale)
+    gb = ChannelSum.apply(gc) if (has_bias and ctx.needs_input_grad[bias_index]) else None
+    return gx, gw, gb
+
+
 class ConvLReLUPN(Function):
-    """(y, rnorm) = PixelNorm(LeakyReLU(conv3x3(resample(x), scale*W) + bias)): one fused kernel forward."""
+    """(y, rnorm) = PixelNorm(LeakyReLU(conv3x3(resample(x), scale*W) + bias)): one fused kernel forward.
+    Optional `in_link` / `out_link` (PNLink): see `first_order_only`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resample, scale, slope):
+    def forward(ctx, x, weight, bias, resample, scale, slope, in_link=None, out_link=None):
         ctx.set_materialize_grads(False)
         x = _c(x)
         y, rn = _run_conv(x, weight, bias, resample, scale, 1, slope)
         ctx.save_for_backward(x, weight, y, rn)
         ctx.has_bias = bias is not None
         ctx.cfg = (resample, scale, slope)
+        ctx.n_in = 6 + (in_link is not None or out_link is not None) * 2
+        if in_link is not None and in_link.y is not x:
+            raise RuntimeError("PixelNorm hand-off: the conv's input is not the linked producer's output")
+        ctx.in_link, ctx.out_link = in_link, out_link
+        if out_link is not None:
+            out_link.y, out_link.rn, out_link.slope, out_link.fused = y, rn, slope, False
         return y, rn
 
     @staticmethod
     def backward(ctx, gy, gr):
         x, weight, y, rn = ctx.saved_tensors
         resample, scale, slope = ctx.cfg
+        pad = (None,) * (ctx.n_in - 3)
         if gy is None and gr is None:
-            return None, None, None, None, None, None
-        if gy is None:
-            gy = torch.zeros_like(y)
-        gc = LReLUPNBwd.apply(gy, gr, y, rn, slope)
-        gx = ConvDgrad.apply(gc, weight, resample, scale) if ctx.needs_input_grad[0] else None
-        gw = None
-        if ctx.needs_input_grad[1]:
-            if _accumulates_in_place(weight):
-                _run_wgrad(x, _c(gc), resample, scale, accumulate_into=weight.grad)   # weight.grad += ..., returns None to autograd
-            else:
-                gw = ConvWgrad.apply(x, gc, resample, scale)
-        gb = ChannelSum.apply(gc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb, None, None, None
+            return (None, None, None) + pad
+        if ctx.out_link is not None and ctx.out_link.fused:
+            if gr is not None:
+                raise RuntimeError("PixelNorm hand-off used together with a gradient w.r.t. the norm output")
+            gc = gy       # the consumer's input-gradient kernel already applied this layer's LeakyReLU->PixelNorm backward
+        else:
+            if gy is None:
+                gy = torch.zeros_like(y)
+            gc = LReLUPNBwd.apply(gy, gr, y, rn, slope)
+        gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
+        return (gx, gw, gb) + pad
+
+
+class ConvLReLUPNToImage(Function):
+    """t = tanh(conv1x1(PixelNorm(LeakyReLU(conv3x3(x, scale*W) + bias)), w_img)): the generator's last block conv and ToImage
+    (models.py:141-146, 262-264) as ONE kernel; the C-channel activation is written only when a backward pass will need it.
+    First order only (it is a generator operator); one colour channel; shapes: `to_image_fusable`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_img, resample, scale, slope, in_link=None):
+        x = _c(x)
+        b, h, w = _conv_out_hw(x, resample)
+        cout, cin = weight.shape[0], weight.shape[1]
+        keep = any(ctx.needs_input_grad)
+        y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32) if keep else None
+        rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if keep else None
+        t = torch.empty((b, h, w, 1), device=x.device, dtype=torch.float32)
+        prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
+        _C.call("ngan_conv3x3_fwd_ex", x, _packed(weight, 0, scale, prec), bias, y, rn, w_img.detach().reshape(-1), None, t,
+                b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, float(slope), PIXELNORM_EPS, prec)
+        if keep:
+            ctx.save_for_backward(x, weight, y, rn, t, w_img)
+        ctx.has_bias = bias is not None
+        ctx.cfg = (resample, scale, slope)
+        if in_link is not None and in_link.y is not x:
+            raise RuntimeError("PixelNorm hand-off: the conv's input is not the linked producer's output")
+        ctx.in_link = in_link
+        return t
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gt):
+        x, weight, y, rn, t, w_img = ctx.saved_tensors
+        resample, scale, slope = ctx.cfg
+        c = y.shape[-1]
+        npix = y.numel() // c
+        gy = torch.empty_like(y)
+        gw_img = torch.empty_like(w_img)
+        ws = torch.empty(1024 * c, device=y.device, dtype=torch.float32)
+        _C.call("ngan_to_image_bwd", _c(gt), t, y, w_img.detach().reshape(1, c), gy, gw_img, ws, npix, c, 1)
+        gc = torch.empty_like(y)
+        _C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, npix, c, float(slope))
+        gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
+        return gx, gw, gb, gw_img, None, None, None, None
+
+
+def to_image_fusable(x, weight, w_img, resample):
+    """can ConvLReLUPNToImage take this layer?  (persistent-kernel shapes, one colour, no resampling)"""
+    if w_img.shape[0] != 1 or resample != RES_NONE:
+        return False
+    b, h, w = _conv_out_hw(x, resample)
+    cout, cin = weight.shape[0], weight.shape[1]
+    prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
+    return _C.conv3x3_epilogue_fused(b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, prec)
 
 
 class Conv(Function):
@@ -653,7 +790,7 @@ class LinearLReLUPN(Function):
     """y (B,S,S,C) = PixelNorm(LeakyReLU(Unflatten(Linear(scale*z, W)))): generator stem, first order."""
 
     @staticmethod
-    def forward(ctx, z, weight, size, scale, slope):
+    def forward(ctx, z, weight, size, scale, slope, out_link=None):
         z = _c(z)
         b, k = z.shape
         s2 = size * size
@@ -664,6 +801,10 @@ class LinearLReLUPN(Function):
         ctx.save_for_backward(z, weight, y, rn)
         ctx.cfg = (s2, c, scale, slope)
         ctx.mark_non_differentiable(rn)
+        ctx.n_in = 5 + (out_link is not None)
+        ctx.out_link = out_link
+        if out_link is not None:
+            out_link.y, out_link.rn, out_link.slope, out_link.fused = y, rn, slope, False
         return y, rn
 
     @staticmethod
@@ -673,8 +814,11 @@ class LinearLReLUPN(Function):
         s2, c, scale, slope = ctx.cfg
         b, k = z.shape
         gy = _c(gy)
-        gc = torch.empty_like(y)
-        _C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, b * s2, c, float(slope))
+        if ctx.out_link is not None and ctx.out_link.fused:
+            gc = gy       # the consuming conv's input-gradient kernel already applied the LeakyReLU->PixelNorm backward
+        else:
+            gc = torch.empty_like(y)
+            _C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, b * s2, c, float(slope))
         gz = gw = None
         if ctx.needs_input_grad[1]:
             if linear_grad_sink is not None:
@@ -685,7 +829,7 @@ class LinearLReLUPN(Function):
         if ctx.needs_input_grad[0]:
             gz = torch.empty_like(z)
             _C.call("ngan_linear_dgrad", gc, weight.detach(), gz, b, k, s2, c, float(scale))
-        return gz, gw, None, None, None
+        return (gz, gw, None, None, None) + (None,) * (ctx.n_in - 5)
 
 
 class FinalDot(Function):

@@ -143,8 +143,11 @@ def test_full_width_pins(ngan, name, conv_precision):
     for k, g in dgrads.items():
         cs = fix["cs/Dgrad/" + k]
         assert abs(float(np.abs(g.astype(np.float64)).sum()) - cs[1]) < 2e-3 * cs[1], ("D", k)
-    # after the critic's first Adam step (each weight moves by ~lr*sign(g), so a rounding-level gradient can flip a
-    # step): the generator gradients seen through the updated critic agree to 1e-2
+    # after the critic's first Adam step (each weight moves by ~lr*sign(g), so a rounding-level critic gradient can flip a
+    # step): the generator gradients seen through the updated critic scatter by 1e-3 .. 1.1e-2 between arithmetic variants
+    # whose critic gradients all agree with the reference to 1e-4 (tools/c2_sensitivity.py prints the four variants: exact
+    # fp32 / split-bf16, fused / unfused backward).  2e-2 bounds that amplification; the tight statement about the
+    # generator's gradients is the pre-update check above (2e-3).
     for k, g in ggrads.items():
         cs = fix["cs/Ggrad/" + k]
-        assert abs(float(np.abs(g.astype(np.float64)).sum()) - cs[1]) < 1e-2 * cs[1], ("G", k)
+        assert abs(float(np.abs(g.astype(np.float64)).sum()) - cs[1]) < 2e-2 * cs[1], ("G", k)

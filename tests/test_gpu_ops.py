@@ -146,6 +146,91 @@ def test_conv_lrelu_pn_all_orders(ngan, case, conv_precision):
     run_both(f_hip, f_ref, t, [k for k in t if k != "x"], x_name="x")
 
 
+LINK_CASES = [
+    # B, H, W (of the producer's output), C0 -> C1 (producer) -> C2 (consumer), consumer's resample
+    (2, 16, 32, 16, 16, 32, 0),        # generic / small kernels
+    (2, 128, 256, 16, 16, 16, 0),      # persistent kernel, fused PixelNorm-backward epilogue
+    (2, 128, 256, 32, 32, 16, 0),
+    (2, 256, 256, 16, 32, 16, 1),      # consumer pools its input: pool-adjoint store + PixelNorm backward at 4 pixels (persistent)
+    (2, 64, 128, 16, 16, 32, 2),       # consumer up-samples its input: up2-adjoint + PixelNorm backward kernel
+    (4, 64, 64, 32, 64, 64, 0),        # split-bf16 mid kernel, all channels in one workgroup
+    (8, 16, 16, 64, 128, 128, 0),      # mid kernel with the channels split over workgroups (PixelNorm backward as a second launch)
+    (4, 32, 32, 32, 64, 128, 1),       # mid kernel, pool-adjoint store
+    (3, 10, 12, 32, 128, 64, 2),       # ragged, 128 channels through the up2-adjoint kernel
+]
+
+
+@pytest.mark.parametrize("case", LINK_CASES)
+def test_pixelnorm_handoff_matches_unfused(ngan, case, conv_precision):
+    """first-order mode (ops.first_order_only + PNLink): the consumer's input-gradient kernel applies the producer's
+    LeakyReLU->PixelNorm backward.  Same operator sequence, so the result must match the unfused backward to rounding."""
+    B, H, W, C0, C1, C2, res = case
+    ops = ngan.ops
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, H, W, C0, device=DEV)
+    w1 = (torch.randn(C1, C0, 3, 3, device=DEV)).requires_grad_()
+    w2 = (torch.randn(C2, C1, 3, 3, device=DEV)).requires_grad_()
+    s1, s2 = 1.3868 / np.sqrt(9 * C0), 1.3868 / np.sqrt(9 * C1)
+
+    def run(linked):
+        xx = x.clone().requires_grad_()
+        if linked:
+            l0, l1 = ops.PNLink(), ops.PNLink()
+            y1, _ = ops.ConvLReLUPN.apply(xx, w1, None, 0, s1, SLOPE, None, l0)
+            y2, _ = ops.ConvLReLUPN.apply(y1, w2, None, res, s2, SLOPE, l0, l1)
+        else:
+            y1, _ = ops.ConvLReLUPN.apply(xx, w1, None, 0, s1, SLOPE)
+            y2, _ = ops.ConvLReLUPN.apply(y1, w2, None, res, s2, SLOPE)
+        torch.manual_seed(1)
+        v = torch.randn_like(y2)
+        g = torch.autograd.grad((y2 * v).sum(), [xx, w1, w2])
+        return [t.detach().clone() for t in g], (l0.fused if linked else None)
+
+    ref, _ = run(False)
+    got, fused = run(True)
+    assert fused is True
+    for name, a, b in zip(["x", "w1", "w2"], got, ref):
+        ok, info = grad_close(a, b, 2e-5)
+        assert ok, (name, info)
+
+
+@pytest.mark.parametrize("case", [(2, 128, 256, 16, 16, False), (2, 128, 256, 32, 16, True), (1, 200, 328, 16, 32, False)])
+def test_conv_to_image_fused(ngan, case, conv_precision):
+    """ops.ConvLReLUPNToImage == ToImage(ConvLReLUPN(x)): forward with and without the stored activation, first-order gradients"""
+    B, H, W, Cin, Cout, use_bias = case
+    ops = ngan.ops
+    torch.manual_seed(3)
+    x = torch.randn(B, H, W, Cin, device=DEV)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV).requires_grad_()
+    bias = (torch.randn(Cout, device=DEV) * 0.3).requires_grad_() if use_bias else None
+    wi = (torch.randn(1, Cout, 1, 1, device=DEV) * 0.3).requires_grad_()
+    scale = 1.3868 / np.sqrt(9 * Cin)
+    assert ops.to_image_fusable(x, w, wi, 0)
+    with torch.no_grad():
+        t_inf = ops.ConvLReLUPNToImage.apply(x, w, bias, wi, 0, scale, SLOPE, None)      # inference form: y is never written
+        y, _ = ops.ConvLReLUPN.apply(x, w, bias, 0, scale, SLOPE)
+        t_ref = ops.ToImage.apply(y, wi)
+    assert rel(t_inf, t_ref) < 1e-5
+    params = [p for p in (w, bias, wi) if p is not None]
+
+    def grads(fused):
+        xx = x.clone().requires_grad_()
+        if fused:
+            t = ops.ConvLReLUPNToImage.apply(xx, w, bias, wi, 0, scale, SLOPE, None)
+        else:
+            yy, _ = ops.ConvLReLUPN.apply(xx, w, bias, 0, scale, SLOPE)
+            t = ops.ToImage.apply(yy, wi)
+        torch.manual_seed(2)
+        return t.detach(), torch.autograd.grad((t * torch.randn_like(t)).sum(), [xx] + params)
+
+    t1, g1 = grads(True)
+    t0, g0 = grads(False)
+    assert rel(t1, t0) < 1e-5
+    for a, b in zip(g1, g0):
+        ok, info = grad_close(a, b, 2e-5)
+        assert ok, info
+
+
 @pytest.mark.parametrize("case", [(2, 8, 8, 16, 32, 0, True), (1, 8, 16, 32, 16, 1, False), (1, 8, 8, 16, 16, 2, False)])
 def test_conv_raw_all_orders(ngan, case, conv_precision):
     B, H, W, Cin, Cout, res, use_bias = case
@@ -206,7 +291,7 @@ def test_to_image_first_order(ngan):
              t, ["x", "w"])
 
 
-@pytest.mark.parametrize("C", [1, 16])
+@pytest.mark.parametrize("C", [1, 16, 128])
 def test_resample_pairs(ngan, C):
     ops = ngan.ops
     torch.manual_seed(4)
