@@ -363,32 +363,46 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         y0 = tyi * THc; x0 = txi * TWc;
     };
     float4 stg[NST];
+    // Tile loads go through a buffer descriptor of the tile's image: a 32-bit byte offset per lane (no 64-bit address arithmetic)
+    // and the hardware range check turns an out-of-range offset into zeros -- the conv padding and the unused staging slots cost
+    // one select on the offset instead of a branch around the load plus four zeroed registers.
+    const unsigned src_img_bytes = (unsigned)((RES == NGAN_RESAMPLE_UP2 ? h * w : a.H * a.W) * K) * 4u;   // host: < 2^32
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    int s_off[NST];      // tile-invariant part of the byte offset (plain input); bilinear input: channel byte offset
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        s_off[i] = RES == NGAN_RESAMPLE_UP2 ? s_ch[i] * 4 : ((s_dy[i] * a.W + s_dx[i]) * K + s_ch[i]) * 4;
     auto issue = [&](int tt) {
         int b, y0, x0;
         decode(tt, b, y0, x0);
+        const float* base = a.x + (long)b * (RES == NGAN_RESAMPLE_UP2 ? h * w : a.H * a.W) * K;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, src_img_bytes, 0x00020000);
         if (RES == NGAN_RESAMPLE_UP2) {
-            const float* base = a.x + (long)b * h * w * K;
             const int ly0 = y0 >> 1, lx0 = x0 >> 1;
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
                 const int ly = min(max(ly0 + s_dy[i], 0), h - 1), lx = min(max(lx0 + s_dx[i], 0), w - 1);
-                stg[i] = (tid + i * 256 < N_SRC) ? ld4(base + ((long)ly * w + lx) * K + s_ch[i]) : f4zero();
+                const unsigned off = (tid + i * 256 < N_SRC) ? (unsigned)((ly * w + lx) * K * 4 + s_off[i]) : OOB;
+                stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
             }
         } else {
-            const float* base = a.x + (long)b * a.H * a.W * K;
+            const int tile_off = (y0 * a.W + x0) * K * 4;
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
-                const int gy = y0 + s_dy[i], gx = x0 + s_dx[i];
-                const bool ok = (tid + i * 256 < N_SRC) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                stg[i] = ok ? ld4(base + ((long)gy * a.W + gx) * K + s_ch[i]) : f4zero();
+                const bool ok = (tid + i * 256 < N_SRC) && (unsigned)(y0 + s_dy[i]) < (unsigned)a.H && (unsigned)(x0 + s_dx[i]) < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(tile_off + s_off[i]) : OOB;
+                stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
             }
         }
     };
     if (t < t_end) issue(t);
 
-    float4 bv[MTW];
+    float4 bv[MTW], wimg[MTW];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) bv[mt] = a.bias ? ld4(a.bias + mt * 16 + q * 4) : f4zero();
+    for (int mt = 0; mt < MTW; ++mt) {
+        bv[mt] = a.bias ? ld4(a.bias + mt * 16 + q * 4) : f4zero();
+        wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + mt * 16 + q * 4) : f4zero();
+    }
     const float inv_n = 1.0f / (float)N;
 
     while (t < t_end) {
@@ -428,6 +442,23 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         __syncthreads();
         const int tn = t + nper;
         if (tn < t_end) issue(tn);   // in flight while this tile is computed
+        // PixelNorm-backward epilogue: its operands (this tile's pixels of the producer's output and norm) are requested now,
+        // so that they arrive during the MFMAs instead of stalling the epilogue
+        constexpr bool PRE = EPI == EPI_PN_BWD && OUTMODE == 0 && MTW * KG > 1;   // (the 16 -> 16 instance has no registers to spare: 1.7x slower with it)
+        float4 yy_pre[PRE ? 4 : 1][MTW];
+        float rn_pre[PRE ? 4 : 1];
+        if (PRE) {
+            const long img0 = (long)b * a.H * a.W;
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) {
+                const int gy = y0 + wave * 2 + (pg >> 1), gx = x0 + (pg & 1) * 16 + p;
+                const bool valid = gy < a.H && gx < a.W;
+                const long pix = img0 + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) yy_pre[pg][mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
+                rn_pre[pg] = a.arn[pix];
+            }
+        }
 
         f32x4 acc[4][MTW];
 #pragma unroll
@@ -485,6 +516,13 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         }
         // ---- epilogue (same math as conv3x3_kernel with WN = 1; reciprocal square root instead of sqrt + divide) ----
         const long img = (long)b * a.H * a.W;
+        float timg = 0.f;
+        __amdgpu_buffer_rsrc_t y_rsrc, rn_rsrc;
+        if (OUTMODE == 0 && (EPI != EPI_TO_IMAGE || a.y)) {
+            y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img * N, 0, (unsigned)(a.H * a.W * N) * 4u, 0x00020000);
+            if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE)
+                rn_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rn + img, 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
+        }
 #pragma unroll
         for (int pg = 0; pg < 4; ++pg) {
             const int row = wave * 2 + (pg >> 1), col = (pg & 1) * 16 + p;
@@ -510,38 +548,48 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 const float inv = __builtin_amdgcn_rsqf(m);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) v[mt] = f4scale(v[mt], inv);
-                if (valid && q == 0 && (EPI == EPI_LRELU_PN || a.y)) a.rn[img + (long)gy * a.W + gx] = m * inv;
+                if (EPI == EPI_LRELU_PN || a.y)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m * inv), rn_rsrc, (valid && q == 0) ? (unsigned)((gy * a.W + gx) * 4) : OOB, 0, 0);
             }
             if (EPI == EPI_TO_IMAGE) {
                 float d = 0.f;
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) d += f4dot(v[mt], ld4(a.ay + mt * 16 + q * 4));
+                for (int mt = 0; mt < MTW; ++mt) d += f4dot(v[mt], wimg[mt]);
                 d += __shfl_xor(d, 16, 64);
                 d += __shfl_xor(d, 32, 64);
-                if (valid && q == 0) a.aout[img + (long)gy * a.W + gx] = tanhf(d);
+                if (q == pg) timg = d;          // all four q-lanes hold pixel group pg's sum; lane group q keeps the one it will finish
             }
             if (EPI == EPI_PN_BWD && OUTMODE == 0) {
                 // backward of the LeakyReLU -> PixelNorm that produced this layer's input, applied to the gradient just computed
-                const long pix = img + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
                 float4 yy[MTW];
+                float rr;
+                if (PRE) {
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) yy[mt] = yy_pre[PRE ? pg : 0][mt];
+                    rr = rn_pre[PRE ? pg : 0];
+                } else {
+                    const long pix = img + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) yy[mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
+                    rr = a.arn[pix];
+                }
                 float s = 0.f;
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) {
-                    yy[mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
-                    s += f4dot(v[mt], yy[mt]);
-                }
+                for (int mt = 0; mt < MTW; ++mt) s += f4dot(v[mt], yy[mt]);
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
                 s *= inv_n;
-                const float inv_r = 1.0f / a.arn[pix];
+                const float inv_r = 1.0f / rr;
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) v[mt] = pn_bwd4(v[mt], yy[mt], s, inv_r, a.slope);
             }
             if (OUTMODE == 0) {
-                if (valid && (EPI != EPI_TO_IMAGE || a.y)) {
-                    float* o = a.y + (img + (long)gy * a.W + gx) * N + q * 4;
+                if (EPI != EPI_TO_IMAGE || a.y) {
+                    // stores through the output image's descriptor: an invalid (off-image) pixel gets an out-of-range offset
+                    const unsigned off = valid ? (unsigned)(((gy * a.W + gx) * N + q * 4) * 4) : OOB;
 #pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) st4(o + mt * 16, v[mt]);
+                    for (int mt = 0; mt < MTW; ++mt)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[mt]), y_rsrc, off + (valid ? mt * 64 : 0), 0, 0);
                 }
             } else {
                 const long W2 = 2L * a.W;
@@ -573,6 +621,13 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                     }
                 }
             }
+        }
+        if (EPI == EPI_TO_IMAGE) {
+            // one tanh per lane instead of four: lane group q finishes pixel group q (same tanhf as the standalone ToImage kernel)
+            const int row = wave * 2 + (q >> 1), col = (q & 1) * 16 + p;
+            const int gy = y0 + row, gx = x0 + col;
+            const float tv = tanhf(timg);
+            if (gy < a.H && gx < a.W) a.aout[img + (long)gy * a.W + gx] = tv;
         }
         t = tn;
     }
@@ -1209,7 +1264,8 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
     ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, 0, 0, slope, eps, aux_in, aux_rn, aux_out};
     hipStream_t s = (hipStream_t)stream;
     if (persist_eligible(B, H, W, K, N, resample)) {
-        // large image, few channels: persistent pipelined kernel
+        // large image, few channels: persistent pipelined kernel (32-bit byte offsets inside one image)
+        NGAN_REQUIRE((long)H * W * (K > N ? K : N) * 16 < (1L << 32), NGAN_ERR_SHAPE, "conv3x3_fwd: one image must stay below 1 GiB (H=%d W=%d)", H, W);
         if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, precision, s)
                                     : dispatch_persist<1, 2>(a, resample, epilogue, out_mode, precision, s);
         return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, precision, s)

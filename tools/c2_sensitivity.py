@@ -28,6 +28,14 @@ for prec in ("f32", "bf16x3"):
         x = torch.rand(64, 1, 64, 64) * 2 - 1
         G.to("cuda:0"); D.to("cuda:0")
         fx = dict(fix); fx["real"] = x.numpy()
+        G.zero_grad()
+        g_pre, _ = ngan.loss_functions.G_W_loss(G, D)(x.to("cuda:0"), z=torch.from_numpy(fix["z_g"]).to("cuda:0"))
+        g_pre.backward()
+        pre = {k: abs(float(p.grad.double().abs().sum()) - fix["cs/Ggrad_pre/" + k][1]) / fix["cs/Ggrad_pre/" + k][1]
+               for k, p in G.named_parameters() if p.grad is not None}
+        wp = sorted(pre.items(), key=lambda kv: -kv[1])[:3]
+        print(f"{prec:7s} fusion={fusion!s:5s} G-grad BEFORE the D update, worst: " + ", ".join(f"{k}={v:.2e}" for k, v in wp))
+        G.zero_grad(); D.zero_grad()
         scal, norms, dgrads, ggrads = T.run_step_losses(ngan, G, D, fx)
         errs = {k: abs(float(np.abs(g.astype(np.float64)).sum()) - fix["cs/Ggrad/" + k][1]) / fix["cs/Ggrad/" + k][1] for k, g in ggrads.items()}
         derr = {k: abs(float(np.abs(g.astype(np.float64)).sum()) - fix["cs/Dgrad/" + k][1]) / fix["cs/Dgrad/" + k][1] for k, g in dgrads.items()}
