@@ -41,17 +41,28 @@ class ConvProbe:
 
     @staticmethod
     def wants(name, args):
-        return name == "ngan_conv3x3_fwd"
+        return name in ("ngan_conv3x3_fwd", "ngan_conv3x3_fwd_ex")
 
     def add(self, name, args, e0, e1):
-        b, h, w, k, n, resample, epilogue, out_mode = args[5:13]
-        key = self.name_of(b, h, w, k, n, resample, epilogue, out_mode, args[15])   # the template instance, as rocprofv3 names it
+        o = 8 if name == "ngan_conv3x3_fwd_ex" else 5          # fwd_ex carries three more pointers (include/ngan.h)
+        b, h, w, k, n, resample, epilogue, out_mode = args[o:o + 8]
+        key = self.name_of(b, h, w, k, n, resample, epilogue, out_mode, args[o + 10])   # the template instance, as rocprofv3 names it
         # algorithmic work of one launch: 2*9*K*N flop per output pixel; bytes = the input read once
         # (K channels per source pixel; 1/4 of the pixels for bilinear input, 4x for pooled), the output written once
-        # (4x the pixels for the pool-adjoint store) and the per-pixel norm when the epilogue produces it
+        # (4x the pixels for the pool-adjoint store; not at all when the ToImage epilogue runs without a stored activation), the
+        # per-pixel norm when the epilogue produces it, the producer's output and norm read by the PixelNorm-backward epilogue,
+        # the image written by the ToImage epilogue
         pix = b * h * w
         src = pix * (4 if resample == 1 else 0.25 if resample == 2 else 1)
-        nbytes = 4.0 * (src * k + pix * n * (4 if out_mode else 1) + (pix if epilogue else 0))
+        opix = pix * (4 if out_mode else 1)
+        y_written = args[3] is not None
+        nbytes = 4.0 * (src * k + (opix * n if y_written else 0))
+        if epilogue == 1 or (epilogue == 3 and y_written):
+            nbytes += 4.0 * pix
+        if epilogue == 2:
+            nbytes += 4.0 * (opix * n + opix)
+        if epilogue == 3:
+            nbytes += 4.0 * pix
         self.records.append((key, 2.0 * 9 * k * n * pix, nbytes, e0, e1))
 
     def summary(self):
@@ -129,11 +140,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    device = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: NGAN_REHEARSAL_BACKEND=gloo runs every rank on cuda:0 with the collectives staged through the
+    # host (same step driver, same segmented graph capture; the numbers mean nothing).  The real run is RCCL, one rank per GPU.
+    rehearsal = os.environ.get("NGAN_REHEARSAL_BACKEND", "")
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(rehearsal)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     pkg = load_package()
     pkg._C.lib()
@@ -220,13 +237,13 @@ def main():
             # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3
             # passes over this same command; committed summary, see profiles/README.md).  null if no summary for this mode.
             traffic, traffic_src = None, None
-            tfile = os.path.join(ROOT, "profiles", f"r01_traffic_{args.precision}.json")
+            tfile = os.path.join(ROOT, "profiles", f"r01_d_traffic_{args.precision}.json")
             if os.path.exists(tfile) and args.res == 512 and args.batch == 16:
                 with open(tfile) as fh:
                     tk = json.load(fh)["kernels"].get(dom)
                 if tk:
                     traffic, traffic_src = tk["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
-            if dom.rstrip(">").endswith(", 1"):   # split-bf16 instance: ~5x the fp32 MFMA rate, so HBM is the binding roof
+            if "mid_kernel" in dom or ("persist" in dom and dom.rstrip(">").endswith(", 1")):   # split-bf16 instance: ~5x the fp32 MFMA rate, so HBM is the binding roof
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                    "algorithmic_bytes_per_launch": d["gbs"] * 1e9 * d["avg_us"] * 1e-6, "launches": d["launches"],

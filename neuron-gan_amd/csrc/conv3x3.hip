@@ -1235,7 +1235,8 @@ extern "C" int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, in
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const bool persist = persist_eligible(B, H, W, K, N, resample);
     if (epilogue == EPI_TO_IMAGE) return persist && resample == 0 && out_mode == 0 ? 1 : 0;
-    if (epilogue == EPI_PN_BWD) return (persist && resample == 0) || (precision == 1 && resample == 0 && ngan::conv3x3_mid_eligible(B, H, W, K, N)) ? 1 : 0;
+    if (epilogue == EPI_PN_BWD)
+        return (persist && resample == 0) || (precision == 1 && resample == 0 && ngan::conv3x3_mid_fuses_epilogue(B, H, W, K, N)) ? 1 : 0;
     return 0;
 }
 
@@ -1302,7 +1303,7 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     const int ci = pick_cfg(mti, B, H, W);
     if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0)
         snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
-                 out_mode ? 0 : epilogue, out_mode, precision);
+                 (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision);
     else if (precision == 1 && ngan::conv3x3_mid_eligible(B, H, W, K, N))
         return ngan::conv3x3_mid_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, buf, len);
     else {

@@ -342,6 +342,10 @@ bool conv3x3_mid_eligible(int B, int H, int W, int K, int N) {
     return B > 0 && H > 0 && W > 0 && (K == 32 || K == 64 || K == 128) && (N == 32 || N == 64 || N == 128);
 }
 
+bool conv3x3_mid_fuses_epilogue(int B, int H, int W, int K, int N) {
+    return conv3x3_mid_eligible(B, H, W, K, N) && mid_slice(B * ceil_div(W, 16) * ceil_div(H, 4), N) == N;
+}
+
 int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, const float* aux_in,
                        const float* aux_rn, int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
                        float slope, float eps, hipStream_t s) {

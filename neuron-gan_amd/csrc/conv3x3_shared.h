@@ -61,6 +61,7 @@ __device__ __forceinline__ float4 load_resampled(const float* __restrict__ x, in
 // conv3x3_mid.hip: split-bf16 kernel for many-channel layers on small images (K, N multiples of 32, up to 128)
 namespace ngan {
 bool conv3x3_mid_eligible(int B, int H, int W, int K, int N);
+bool conv3x3_mid_fuses_epilogue(int B, int H, int W, int K, int N);   // all N channels of a pixel in one workgroup?
 int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, const float* aux_in,
                        const float* aux_rn, int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
                        float slope, float eps, hipStream_t s);

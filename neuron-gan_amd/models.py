@@ -326,7 +326,8 @@ def _exec(steps, x, link=None, to_image=None):
             _, m, res, slope = st
             if (idx == last and to_image is not None and ops.first_order_enabled()
                     and ops.to_image_fusable(x, m.weight, to_image.layers[0].weight, res)):
-                t = ops.ConvLReLUPNToImage.apply(x, m.weight, m.bias, to_image.layers[0].weight, res, m.scale_value, slope, link)
+                t = ops.ConvLReLUPNToImage.apply(x, m.weight, m.bias, to_image.layers[0].weight, res, m.scale_value, slope, link,
+                                                 torch.is_grad_enabled())
                 return t, None
             out_link = ops.PNLink() if linking else None
             if link is not None or out_link is not None:

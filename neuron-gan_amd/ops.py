@@ -386,11 +386,13 @@ class ConvLReLUPNToImage(Function):
     First order only (it is a generator operator); one colour channel; shapes: `to_image_fusable`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_img, resample, scale, slope, in_link=None):
+    def forward(ctx, x, weight, bias, w_img, resample, scale, slope, in_link=None, keep=True):
+        # keep: will a backward pass follow?  (the caller passes torch.is_grad_enabled(): inside forward() grad mode is always
+        # off and needs_input_grad mirrors requires_grad even under no_grad)
         x = _c(x)
         b, h, w = _conv_out_hw(x, resample)
         cout, cin = weight.shape[0], weight.shape[1]
-        keep = any(ctx.needs_input_grad)
+        keep = bool(keep) and any(ctx.needs_input_grad)
         y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32) if keep else None
         rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if keep else None
         t = torch.empty((b, h, w, 1), device=x.device, dtype=torch.float32)
@@ -420,7 +422,7 @@ class ConvLReLUPNToImage(Function):
         gc = torch.empty_like(y)
         _C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, npix, c, float(slope))
         gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
-        return gx, gw, gb, gw_img, None, None, None, None
+        return gx, gw, gb, gw_img, None, None, None, None, None
 
 
 def to_image_fusable(x, weight, w_img, resample):

@@ -207,7 +207,7 @@ def test_conv_to_image_fused(ngan, case, conv_precision):
     scale = 1.3868 / np.sqrt(9 * Cin)
     assert ops.to_image_fusable(x, w, wi, 0)
     with torch.no_grad():
-        t_inf = ops.ConvLReLUPNToImage.apply(x, w, bias, wi, 0, scale, SLOPE, None)      # inference form: y is never written
+        t_inf = ops.ConvLReLUPNToImage.apply(x, w, bias, wi, 0, scale, SLOPE, None, False)      # inference form: y is never written
         y, _ = ops.ConvLReLUPN.apply(x, w, bias, 0, scale, SLOPE)
         t_ref = ops.ToImage.apply(y, wi)
     assert rel(t_inf, t_ref) < 1e-5
@@ -216,7 +216,7 @@ def test_conv_to_image_fused(ngan, case, conv_precision):
     def grads(fused):
         xx = x.clone().requires_grad_()
         if fused:
-            t = ops.ConvLReLUPNToImage.apply(xx, w, bias, wi, 0, scale, SLOPE, None)
+            t = ops.ConvLReLUPNToImage.apply(xx, w, bias, wi, 0, scale, SLOPE, None, True)
         else:
             yy, _ = ops.ConvLReLUPN.apply(xx, w, bias, 0, scale, SLOPE)
             t = ops.ToImage.apply(yy, wi)
