@@ -197,6 +197,17 @@ int ngan_adam_step(float* p, const float* g, float* m, float* v, const long* seg
                    const int* seg_active, float* seg_step, int n_seg, const int* chunk_seg, const long* chunk_off,
                    int n_chunks, const float* hyper, void* stream);
 
+/* ---- on-device input pipeline: data/NeuronDataset.py:112-126, 149-164 (torchvision RandomAffine / RandomVerticalFlip /
+ * ColorJitter / CenterCrop / Renormalize / Resize(antialias) per image) as two launches per batch, one colour channel.
+ *   src     (N, P, P) padded images in [0, 1];  idx (B) int32: which image each sample uses
+ *   params  B records { float cos, sin, tx, ty, brightness, contrast; int flip, contrast_first; }   (32 bytes)
+ *           source pixel = nearest([cos, sin; -sin, cos] * (dst - (tx, ty))) in centred pixel coordinates, 0 outside
+ *   out     (B, S, S) in [-1, 1]: centre crop R x R of the P x P canvas, renormalised, down-sampled to S x S (S divides R) with the
+ *           antialiased bilinear (triangle) filter;  workspace: ngan_augment_workspace_bytes(B, P) bytes */
+size_t ngan_augment_workspace_bytes(int B, int P);
+int ngan_augment_batch(const float* src, const int* idx, const void* params, float* workspace, float* out,
+                       int N, int B, int P, int R, int S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,9 +9,10 @@ The directory name carries a hyphen, so it is loaded under the module name `neur
     loss_functions.py  D_W_loss / G_W_loss / D_grad_pen_loss
     utils.py           sample_latent_vec
     configs/config.py  module-as-singleton configuration
-    train.py           the G/D step driver (flat parameters, fused Adam, data-parallel gradient exchange)
+    train.py           the G/D step driver (flat parameters, fused Adam, data-parallel gradient exchange), epoch driver, CLI
+    data.py            device-resident dataset with the reference's augmentation chain as one launch per batch
 """
-from . import _C, ops, utils, models, loss_functions, train  # noqa: F401
+from . import _C, ops, utils, models, loss_functions, train, data  # noqa: F401
 from .configs import config  # noqa: F401
 
 __version__ = "0.1.0"

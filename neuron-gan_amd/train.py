@@ -215,6 +215,7 @@ class PGGANTrainer:
             self.opt_d.set_grad_scale(1.0 / self.world)
             self.enable_stem_exchange()
         self.force_exchange = False
+        self.last_z_g = None
         self.refresh_stage()
         self._graph = None
         ops.bump_weight_epoch()
@@ -297,7 +298,7 @@ class PGGANTrainer:
         for p in d_params:  # the reference also back-propagates into the critic's weights here and discards the result
             p.requires_grad_(False)
         try:
-            loss, _ = self.g_loss(real, z=self._latent(b, z))  # train.py:376
+            loss, self.last_z_g = self.g_loss(real, z=self._latent(b, z))  # train.py:376
             ops.linear_grad_sink = self.stem.sink if self.stem is not None else None
             try:
                 with ops.deferred_wgrad():
@@ -319,6 +320,8 @@ class PGGANTrainer:
         stats = {}
         for _ in range(self.n_critic):  # train.py:356
             stats.update(self.d_step(real, z_d, z_gp, eps))
+        if self.n_critic == 0:          # adaptive critic schedule chose no critic step: losses for monitoring only (train.py:369-372)
+            stats.update(self.d_compute(real, z_d, z_gp, eps))
         stats.update(self.g_step(real, z_g))
         return stats
 
@@ -451,10 +454,9 @@ def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_fina
     epoch late through pinned memory, so the host never stalls the launch stream; a NaN loss raises ValueError like the
     reference's loss modules do (loss_functions.py:35-41, 70-72)."""
     import time
-    if cfg.adapt_critic:
-        raise NotImplementedError("adapt_critic (utils.Calculate_D_steps) is off by default and not part of the hot path")
-    if cfg.sim_loss_lambda > 0:
-        raise NotImplementedError("similarity loss (lambda = 0 by default) is not part of the hot path")
+    from .utils import Calculate_D_steps, similarity_loss
+    adapt_period = 100                                                # Disc_adapt_update_period, train.py:190
+    sim_lambda = float(cfg.sim_loss_lambda)                           # train.py:300
     G, D = trainer.G, trainer.D
     dev = trainer.device
     epoch_final = epoch_final if epoch_final is not None else cfg.N_epochs + 1
@@ -494,19 +496,35 @@ def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_fina
         if trainer.start_epoch(epoch, cfg.transit_sch):
             dataset.set_image_size(G.image_size)
             graph_shape = None
+        # number of critic steps this epoch (train.py:336-340); the score series lags one epoch here (deferred read-back)
+        if cfg.adapt_critic and len(series["score_real"]) > adapt_period:
+            n_d_steps = Calculate_D_steps(series["score_real"], series["score_fake"], 0, cfg.n_critic, Period=adapt_period)
+        else:
+            n_d_steps = cfg.n_critic
+        if cfg.sim_loss_lambda_decay_rate > 0 and sim_lambda > 0:     # train.py:343-348
+            sim_lambda = cfg.sim_loss_lambda * (1 - cfg.sim_loss_lambda_decay_rate) ** (epoch - 1) if sim_lambda > 1e-5 else 0.0
         acc = torch.zeros(len(names), device=dev)
         order = torch.randperm(n_images).tolist()                     # DataLoader(shuffle=True), train.py:153
         for i in range(0, n_images, cfg.batch_size):
-            images = torch.stack([dataset[j] for j in order[i:i + cfg.batch_size]]).to(dev)
+            if hasattr(dataset, "batch"):                          # device dataset: one augmentation launch per batch (data.py)
+                images = dataset.batch(order[i:i + cfg.batch_size])
+            else:
+                images = torch.stack([dataset[j] for j in order[i:i + cfg.batch_size]]).to(dev)
             b = images.size(0)
-            if use_graph and trainer.device_latents and cfg.n_critic == 1:
+            if use_graph and trainer.device_latents and n_d_steps == 1:
                 if graph_shape != tuple(images.shape):
                     trainer.capture(images, warmup=1)                # (re)capture after growth or a ragged last batch
                     graph_shape = tuple(images.shape)
                 stats = trainer.replay(images)
             else:
+                trainer.n_critic = n_d_steps
                 stats = trainer.train_iteration(images)
-            acc += b * torch.stack([stats["score_real"], stats["score_fake"], stats["D_loss"], stats["G_loss"],
+            g_loss = stats["G_loss"]
+            if sim_lambda > 0:
+                # the reference adds similarity_loss(real images, latents) to the generator loss (train.py:379-381); it depends on
+                # neither network, so it changes the monitored value only
+                g_loss = g_loss + similarity_loss(images, trainer.last_z_g, sim_lambda)
+            acc += b * torch.stack([stats["score_real"], stats["score_fake"], stats["D_loss"], g_loss,
                                     stats["D_grad_pen"].float()])
         slot = epoch & 1
         consume(slot)

@@ -192,3 +192,28 @@ def plot_gen_samples(Generator, eval_noise=None, N_images=16, seed=None, filenam
         arr = (grid.clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).numpy()
         Image.fromarray(arr[:, :, 0] if arr.shape[2] == 1 else arr).save(filename)
     return grid
+
+
+def Calculate_D_steps(Loss_real, Loss_fake, N_min, N_max, Period):
+    """Number of critic steps for the next epoch (reference utils.py:105-120): the critic is trained less when the gap between
+    the real and fake scores is large compared to the spread of the real score over the last `Period` epochs."""
+    if Loss_real and Loss_fake:
+        real_std = np.std(Loss_real[-Period:])
+        diff = np.mean(np.abs(np.subtract(Loss_fake[-Period:], Loss_real[-Period:])))
+        n_steps = np.round(real_std / diff * N_max)
+        n_steps = np.min([n_steps, N_max])
+        n_steps = np.max([n_steps, N_min])
+        return int(n_steps)
+    return N_max
+
+
+def similarity_loss(images_batch, Z_batch, Lambda=1.0):
+    """Reference loss_functions.py:185-205: squared difference between the pairwise cosine similarities of the latents and of the
+    images.  The reference evaluates it on the REAL batch and the latents (train.py:380), so it carries no gradient to either net:
+    it is a monitored number, computed here with a few tiny torch matmuls (B x B), off the hot path."""
+    b = images_batch.size(0)
+    im = images_batch.reshape(b, -1)
+    z = Z_batch.reshape(b, -1)
+    im = im / im.norm(2, dim=1, keepdim=True)
+    z = z / z.norm(2, dim=1, keepdim=True)
+    return Lambda * torch.pow(z @ z.t() - im @ im.t(), 2).sum() / (b * (b - 1))

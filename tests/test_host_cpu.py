@@ -195,3 +195,24 @@ def test_flat_params_and_active_set(ngan):
     sd_before = {k: v.clone() for k, v in D.state_dict().items()}
     D.load_state_dict(sd_before)  # in-place copy keeps the views
     assert flat.params[0].data_ptr() == flat.flat.data_ptr()
+
+
+def test_adaptive_critic_schedule_and_similarity_monitor():
+    """utils.Calculate_D_steps / similarity_loss restate reference utils.py:105-120 and loss_functions.py:185-205"""
+    import numpy as np
+    import torch
+    from __graft_entry__ import load_package
+    u = load_package().utils
+    assert u.Calculate_D_steps([], [], 0, 5, 100) == 5                          # empty series: maximum
+    assert u.Calculate_D_steps([1., 2., 3., 4.], [0., 0., 0., 0.], 0, 5, 100) == 2     # round(std 1.118 / gap 2.5 * 5)
+    assert u.Calculate_D_steps([1., 1., 1.], [5., 5., 5.], 1, 5, 10) == 1       # constant real score: clamps to N_min
+    assert u.Calculate_D_steps([0., 10.], [0.1, 9.9], 0, 5, 100) == 5           # small gap: clamps to N_max
+    assert u.Calculate_D_steps([0.] * 50 + [1., 3.], [0.] * 50 + [1., 1.], 0, 4, 2) == 4   # only the last `Period` entries count
+    torch.manual_seed(0)
+    x, z = torch.randn(6, 1, 8, 8), torch.randn(6, 32)
+    xm = (x.reshape(6, -1).double().numpy())
+    zm = z.double().numpy()
+    xm = xm / np.linalg.norm(xm, axis=1, keepdims=True)
+    zm = zm / np.linalg.norm(zm, axis=1, keepdims=True)
+    want = 0.7 * ((zm @ zm.T - xm @ xm.T) ** 2).sum() / 30
+    assert abs(float(u.similarity_loss(x, z, 0.7)) - want) < 1e-6
