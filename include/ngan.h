@@ -119,6 +119,10 @@ int ngan_lrelu_pixelnorm_fwd(const float* c, const float* bias, float* y, float*
                              float slope, float eps, void* stream);
 int ngan_lrelu_pixelnorm_bwd(const float* gy, const float* gr, const float* y, const float* rnorm, float* gc,
                              long npix, int C, float slope, void* stream);
+/* bwd with the incoming gradient given as a sum of two tensors (gy + gy2; gy2 may be NULL): in the gradient-penalty pass the
+ * gradient w.r.t. a layer output has two contributions, and summing them here saves a separate elementwise pass */
+int ngan_lrelu_pixelnorm_bwd2(const float* gy, const float* gy2, const float* gr, const float* y, const float* rnorm, float* gc,
+                              long npix, int C, float slope, void* stream);
 int ngan_lrelu_pixelnorm_bwdbwd(const float* h, const float* gy, const float* y, const float* rnorm,
                                 float* ggy, float* gy_out, float* gr_out, long npix, int C, float slope, void* stream);
 
@@ -141,6 +145,10 @@ int ngan_from_image_dw(const float* x, const float* g, float* gw, float* gb, flo
 int ngan_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, void* stream);
 int ngan_to_image_bwd(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
                       float* workspace, long npix, int C, int Ncol, void* stream);
+/* to_image_bwd where the ToImage input is the output y of a LeakyReLU -> PixelNorm (norms rnorm): gc receives the gradient w.r.t.
+ * that operator's input, i.e. the PixelNorm/LeakyReLU backward is applied before the store (one pass over the activation) */
+int ngan_to_image_bwd_pnbwd(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
+                            float* gw, float* workspace, long npix, int C, int Ncol, float slope, void* stream);
 
 /* ---- resampling: models.py:87-89 (F.interpolate bilinear, align_corners=None) and models.py:254 (AvgPool2d(2)) --
  * (h, w) is always the LOW resolution; adjoint = transpose of the linear map. */

@@ -21,6 +21,7 @@ SIGNATURES = {
     "ngan_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "ngan_lrelu_pixelnorm_fwd": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
     "ngan_lrelu_pixelnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "ngan_lrelu_pixelnorm_bwd2": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P],
     "ngan_lrelu_pixelnorm_bwdbwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P],
     "ngan_channel_sum": [_P, _P, _P, _L, _I, _F, _P],
     "ngan_from_image_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -28,6 +29,7 @@ SIGNATURES = {
     "ngan_from_image_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ngan_to_image_fwd": [_P, _P, _P, _L, _I, _I, _P],
     "ngan_to_image_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "ngan_to_image_bwd_pnbwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P],
     "ngan_up2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "ngan_up2_adjoint": [_P, _P, _I, _I, _I, _I, _P],
     "ngan_up2_adjoint_pnbwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],

@@ -32,12 +32,14 @@ __global__ __launch_bounds__(256) void pn_fwd_kernel(const float* __restrict__ c
 template <int LPP>
 __global__ __launch_bounds__(256) void pn_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ gr,
                                                      const float* __restrict__ y, const float* __restrict__ rn,
-                                                     float* __restrict__ gc, long npix, int C, float slope) {
+                                                     float* __restrict__ gc, long npix, int C, float slope,
+                                                     const float* __restrict__ gy2) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long pix = gid / LPP;
     const int sub = (int)(gid % LPP);
     const bool ok = pix < npix;
-    const float4 g = ok ? ld4(gy + pix * C + sub * 4) : f4zero();
+    float4 g = ok ? ld4(gy + pix * C + sub * 4) : f4zero();
+    if (gy2 && ok) g = f4add(g, ld4(gy2 + pix * C + sub * 4));      // a second contribution to the same gradient, summed here
     const float4 yy = ok ? ld4(y + pix * C + sub * 4) : f4zero();
     const float r = ok ? rn[pix] : 1.f;
     const float inv_c = 1.0f / (float)C;
@@ -116,12 +118,17 @@ extern "C" int ngan_lrelu_pixelnorm_fwd(const float* c, const float* bias, float
     return ngan::launch_status("ngan_lrelu_pixelnorm_fwd");
 }
 
-extern "C" int ngan_lrelu_pixelnorm_bwd(const float* gy, const float* gr, const float* y, const float* rnorm, float* gc,
-                                        long npix, int C, float slope, void* stream) {
+extern "C" int ngan_lrelu_pixelnorm_bwd2(const float* gy, const float* gy2, const float* gr, const float* y, const float* rnorm,
+                                         float* gc, long npix, int C, float slope, void* stream) {
     NGAN_REQUIRE(gy && y && rnorm && gc, NGAN_ERR_ARG, "lrelu_pixelnorm_bwd: null pointer");
     NGAN_REQUIRE(npix > 0 && lpp_ok(C), NGAN_ERR_SHAPE, "lrelu_pixelnorm_bwd: npix=%ld C=%d unsupported", npix, C);
-    PN_DISPATCH(pn_bwd_kernel, gy, gr, y, rnorm, gc, npix, C, slope);
+    PN_DISPATCH(pn_bwd_kernel, gy, gr, y, rnorm, gc, npix, C, slope, gy2);
     return ngan::launch_status("ngan_lrelu_pixelnorm_bwd");
+}
+
+extern "C" int ngan_lrelu_pixelnorm_bwd(const float* gy, const float* gr, const float* y, const float* rnorm, float* gc,
+                                        long npix, int C, float slope, void* stream) {
+    return ngan_lrelu_pixelnorm_bwd2(gy, nullptr, gr, y, rnorm, gc, npix, C, slope, stream);
 }
 
 extern "C" int ngan_lrelu_pixelnorm_bwdbwd(const float* h, const float* gy, const float* y, const float* rnorm,

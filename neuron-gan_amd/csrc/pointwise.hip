@@ -227,11 +227,13 @@ __global__ __launch_bounds__(256) void to_image_fwd_kernel(const float* __restri
     }
 }
 
+// rn != nullptr: x is the output of a LeakyReLU -> PixelNorm with norms rn, and gx receives the gradient w.r.t. that operator's
+// INPUT (its backward is applied to the ToImage input-gradient before the store: one pass instead of two over the activation)
 template <int Q>
 __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restrict__ g, const float* __restrict__ t,
                                                            const float* __restrict__ x, const float* __restrict__ w,
                                                            float* __restrict__ gx, float* __restrict__ partial,
-                                                           long npix, int C, int Ncol) {
+                                                           long npix, int C, int Ncol, const float* __restrict__ rn, float slope) {
     __shared__ float4 red[256];
     const int tid = threadIdx.x, sub = tid % Q;
     const long stride = (long)gridDim.x * (256 / Q);
@@ -241,6 +243,8 @@ __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restri
     float4 wv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) wv[k] = k < Ncol ? ld4(w + k * C + sub * 4) : f4zero();
+    // (the trip count is the same for all Q lanes of a pixel group only if npix is a multiple of 256 / Q per stride step; lanes of
+    // one pixel always iterate together, which is all the group shuffle below needs)
     for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) {
         const float4 xv = ld4(x + pix * C + sub * 4);
         float4 o = f4zero();
@@ -252,6 +256,10 @@ __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restri
                 o = f4fma(wv[k], qv, o);
                 acc[k] = f4fma(xv, qv, acc[k]);
             }
+        if (rn) {
+            const float sdot = group_sum<Q>(f4dot(o, xv)) * (1.0f / (float)C);
+            o = pn_bwd4_pw(o, xv, sdot, 1.0f / rn[pix], slope);
+        }
         st4(gx + pix * C + sub * 4, o);
     }
 #pragma unroll
@@ -591,14 +599,28 @@ extern "C" int ngan_to_image_fwd(const float* x, const float* w, float* t, long 
     return ngan::launch_status("ngan_to_image_fwd");
 }
 
+static int to_image_bwd_impl(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
+                             float* workspace, long npix, int C, int Ncol, const float* rn, float slope, void* stream);
+
 extern "C" int ngan_to_image_bwd(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
                                  float* workspace, long npix, int C, int Ncol, void* stream) {
+    return to_image_bwd_impl(g, t, x, w, gx, gw, workspace, npix, C, Ncol, nullptr, 0.f, stream);
+}
+
+extern "C" int ngan_to_image_bwd_pnbwd(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
+                                       float* gw, float* workspace, long npix, int C, int Ncol, float slope, void* stream) {
+    NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
+    return to_image_bwd_impl(g, t, y, w, gc, gw, workspace, npix, C, Ncol, rnorm, slope, stream);
+}
+
+static int to_image_bwd_impl(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
+                             float* workspace, long npix, int C, int Ncol, const float* rn, float slope, void* stream) {
     NGAN_REQUIRE(g && t && x && w && gx && gw && workspace, NGAN_ERR_ARG, "to_image_bwd: null pointer");
     NGAN_REQUIRE(npix > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE, "to_image_bwd: npix=%ld C=%d Ncol=%d unsupported",
                  npix, C, Ncol);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = stream_blocks(npix, C / 4);
-#define CALL(QV) hipLaunchKernelGGL((to_image_bwd_kernel<QV>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol)
+#define CALL(QV) hipLaunchKernelGGL((to_image_bwd_kernel<QV>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope)
     Q_DISPATCH(CALL)
 #undef CALL
     int st = ngan::launch_status("ngan_to_image_bwd");

@@ -359,6 +359,7 @@ class ConvLReLUPN(Function):
         ctx.in_link, ctx.out_link = in_link, out_link
         if out_link is not None:
             out_link.y, out_link.rn, out_link.slope, out_link.fused = y, rn, slope, False
+        ctx.stash = GradStash()
         return y, rn
 
     @staticmethod
@@ -366,16 +367,22 @@ class ConvLReLUPN(Function):
         x, weight, y, rn = ctx.saved_tensors
         resample, scale, slope = ctx.cfg
         pad = (None,) * (ctx.n_in - 3)
-        if gy is None and gr is None:
+        extra, ctx.stash.pending = ctx.stash.pending, None      # contribution left by this layer's LReLUPNBwd node (GradStash)
+        if gy is None and gr is None and extra is None:
             return (None, None, None) + pad
         if ctx.out_link is not None and ctx.out_link.fused:
-            if gr is not None:
-                raise RuntimeError("PixelNorm hand-off used together with a gradient w.r.t. the norm output")
+            if gr is not None or extra is not None:
+                raise RuntimeError("PixelNorm hand-off used together with a second-order gradient")
             gc = gy       # the consumer's input-gradient kernel already applied this layer's LeakyReLU->PixelNorm backward
-        else:
+        elif torch.is_grad_enabled():
+            # create_graph pass: a differentiable node; its backward will leave its gradient w.r.t. y in the stash
             if gy is None:
                 gy = torch.zeros_like(y)
-            gc = LReLUPNBwd.apply(gy, gr, y, rn, slope)
+            gc = LReLUPNBwd.apply(gy, gr, y, rn, slope, ctx.stash, None)
+        else:
+            if gy is None:
+                gy, extra = (extra, None) if extra is not None else (torch.zeros_like(y), None)
+            gc = LReLUPNBwd.apply(gy, gr, y, rn, slope, None, extra) if extra is not None else LReLUPNBwd.apply(gy, gr, y, rn, slope)
         gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
         return (gx, gw, gb) + pad
 
@@ -415,12 +422,10 @@ class ConvLReLUPNToImage(Function):
         resample, scale, slope = ctx.cfg
         c = y.shape[-1]
         npix = y.numel() // c
-        gy = torch.empty_like(y)
         gw_img = torch.empty_like(w_img)
         ws = torch.empty(1024 * c, device=y.device, dtype=torch.float32)
-        _C.call("ngan_to_image_bwd", _c(gt), t, y, w_img.detach().reshape(1, c), gy, gw_img, ws, npix, c, 1)
-        gc = torch.empty_like(y)
-        _C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, npix, c, float(slope))
+        gc = torch.empty_like(y)      # ToImage backward and the LeakyReLU->PixelNorm backward in one pass over y
+        _C.call("ngan_to_image_bwd_pnbwd", _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, gw_img, ws, npix, c, 1, float(slope))
         gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
         return gx, gw, gb, gw_img, None, None, None, None, None
 
@@ -546,18 +551,33 @@ class LReLUPN(Function):
         return gc, gb, None
 
 
+class GradStash:
+    """Side channel for the gradient penalty's backward pass.  The gradient w.r.t. a layer output y has two contributions there:
+    one from the next conv and one from the backward of this layer's own LReLUPNBwd node (y is an input of that node).  Autograd
+    would add them with an elementwise kernel before calling the layer's backward.  Instead LReLUPNBwd.backward leaves its
+    contribution here and returns None for y, and the layer's backward (which autograd runs afterwards: the node also feeds the
+    layer's norm output, so it is a graph predecessor) hands both tensors to ONE PixelNorm-backward launch that sums them."""
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = None
+
+
 class LReLUPNBwd(Function):
     """gc = m * ((gy - y*mean_c(gy*y))/r + gr*y/C): first-order backward of LeakyReLU->PixelNorm."""
 
     @staticmethod
-    def forward(ctx, gy, gr, y, rn, slope):
+    def forward(ctx, gy, gr, y, rn, slope, stash=None, gy2=None):
         gy, gr = _c(gy), _c(gr)
         ch = y.shape[-1]
         gc = torch.empty_like(y)
-        _C.call("ngan_lrelu_pixelnorm_bwd", gy, gr, y, rn, gc, y.numel() // ch, ch, float(slope))
-        ctx.save_for_backward(gy, y, rn)
+        _C.call("ngan_lrelu_pixelnorm_bwd2", gy, _c(gy2), gr, y, rn, gc, y.numel() // ch, ch, float(slope))
+        if gy2 is None:            # (gy2 only comes from a no-grad pass, which records no graph: see ConvLReLUPN.backward)
+            ctx.save_for_backward(gy, y, rn)
         ctx.had_gr = gr is not None
         ctx.slope = slope
+        ctx.stash = stash
+        ctx.n_in = 5 + (stash is not None or gy2 is not None) * 2
         return gc
 
     @staticmethod
@@ -572,7 +592,11 @@ class LReLUPNBwd(Function):
         gy_out = torch.empty_like(y)
         gr_out = torch.empty_like(rn)
         _C.call("ngan_lrelu_pixelnorm_bwdbwd", h, gy, y, rn, ggy, gy_out, gr_out, y.numel() // ch, ch, float(ctx.slope))
-        return ggy, None, gy_out, gr_out, None
+        pad = (None,) * (ctx.n_in - 5)
+        if ctx.stash is not None and ctx.stash.pending is None:
+            ctx.stash.pending = gy_out          # picked up by the producing layer's backward (GradStash)
+            return (ggy, None, None, gr_out, None) + pad
+        return (ggy, None, gy_out, gr_out, None) + pad
 
 
 # ---------------------------------------------------------------------------------------------------------

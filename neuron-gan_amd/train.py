@@ -456,7 +456,9 @@ def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_fina
     import time
     from .utils import Calculate_D_steps, similarity_loss
     adapt_period = 100                                                # Disc_adapt_update_period, train.py:190
-    sim_lambda = float(cfg.sim_loss_lambda)                           # train.py:300
+    sim_lambda = float(getattr(cfg, 'sim_loss_lambda', 0.0))          # train.py:300
+    sim_decay = float(getattr(cfg, 'sim_loss_lambda_decay_rate', 0.0))
+    adapt_critic = bool(getattr(cfg, 'adapt_critic', False))
     G, D = trainer.G, trainer.D
     dev = trainer.device
     epoch_final = epoch_final if epoch_final is not None else cfg.N_epochs + 1
@@ -497,12 +499,12 @@ def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_fina
             dataset.set_image_size(G.image_size)
             graph_shape = None
         # number of critic steps this epoch (train.py:336-340); the score series lags one epoch here (deferred read-back)
-        if cfg.adapt_critic and len(series["score_real"]) > adapt_period:
+        if adapt_critic and len(series["score_real"]) > adapt_period:
             n_d_steps = Calculate_D_steps(series["score_real"], series["score_fake"], 0, cfg.n_critic, Period=adapt_period)
         else:
             n_d_steps = cfg.n_critic
-        if cfg.sim_loss_lambda_decay_rate > 0 and sim_lambda > 0:     # train.py:343-348
-            sim_lambda = cfg.sim_loss_lambda * (1 - cfg.sim_loss_lambda_decay_rate) ** (epoch - 1) if sim_lambda > 1e-5 else 0.0
+        if sim_decay > 0 and sim_lambda > 0:                          # train.py:343-348
+            sim_lambda = cfg.sim_loss_lambda * (1 - sim_decay) ** (epoch - 1) if sim_lambda > 1e-5 else 0.0
         acc = torch.zeros(len(names), device=dev)
         order = torch.randperm(n_images).tolist()                     # DataLoader(shuffle=True), train.py:153
         for i in range(0, n_images, cfg.batch_size):
