@@ -276,9 +276,14 @@ __device__ __forceinline__ void st_split(float* tile, int idx, float4 v) {
 // PREC = 1: split-bf16 arithmetic (3 x v_mfma_f32_16x16x32_bf16 per fp32 product group, fp32 accumulate): the fp32 input
 // is split into hi/lo bf16 halves while the tile is staged; LDS image per pixel (K = 16): [hi c0-7][hi c8-15][lo c0-7]
 // [lo c8-15] (16 B each, same 64 B and the same rotation as the fp32 image); K = 32: plane 0 = hi, plane 1 = lo.
+constexpr int persist_tile_h(int MTW, int KG) { return MTW * KG == 4 ? 4 : 8; }
+
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
-    constexpr int THc = 8, TWc = 32, HH_ = THc + 2, HW_ = TWc + 2, NPIX = HH_ * HW_, LP = 40;
+    // tile: 8 x 32 pixels, 4 pixel groups of 16 per wave; the 32 -> 32 instances use 4 x 32 (2 groups per wave): their 8-row tile
+    // needs 88 KB of LDS and ~260 registers, i.e. ONE workgroup per CU with nothing to overlap its load / barrier / MFMA phases
+    constexpr int THc = persist_tile_h(MTW, KG), PGW = THc / 2, RPW = THc / 4;
+    constexpr int TWc = 32, HH_ = THc + 2, HW_ = TWc + 2, NPIX = HH_ * HW_, LP = 40;
     constexpr int PH = THc / 2 + 2, PW = TWc / 2 + 2, NPP = PH * PW;
     constexpr int NSTEP = KG == 1 ? 5 : 9;   // bf16x3: K = 32 contraction steps per tile
     constexpr int W_ELEMS = PREC ? NSTEP * MTW * 2 * 256 : 9 * KG * MTW * 256, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
@@ -445,13 +450,13 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         // PixelNorm-backward epilogue: its operands (this tile's pixels of the producer's output and norm) are requested now,
         // so that they arrive during the MFMAs instead of stalling the epilogue
         constexpr bool PRE = EPI == EPI_PN_BWD && OUTMODE == 0 && MTW * KG > 1;   // (the 16 -> 16 instance has no registers to spare: 1.7x slower with it)
-        float4 yy_pre[PRE ? 4 : 1][MTW];
-        float rn_pre[PRE ? 4 : 1];
+        float4 yy_pre[PRE ? PGW : 1][MTW];
+        float rn_pre[PRE ? PGW : 1];
         if (PRE) {
             const long img0 = (long)b * a.H * a.W;
 #pragma unroll
-            for (int pg = 0; pg < 4; ++pg) {
-                const int gy = y0 + wave * 2 + (pg >> 1), gx = x0 + (pg & 1) * 16 + p;
+            for (int pg = 0; pg < PGW; ++pg) {
+                const int gy = y0 + wave * RPW + (pg >> 1), gx = x0 + (pg & 1) * 16 + p;
                 const bool valid = gy < a.H && gx < a.W;
                 const long pix = img0 + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
 #pragma unroll
@@ -460,18 +465,18 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             }
         }
 
-        f32x4 acc[4][MTW];
+        f32x4 acc[PGW][MTW];
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg)
+        for (int pg = 0; pg < PGW; ++pg)
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (PREC) {
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
-                bf16x8 xh[4], xl[4];
+                bf16x8 xh[PGW], xl[PGW];
 #pragma unroll
-                for (int pg = 0; pg < 4; ++pg) {
-                    const int row = wave * 2 + (pg >> 1);
+                for (int pg = 0; pg < PGW; ++pg) {
+                    const int row = wave * RPW + (pg >> 1);
                     const int base = (row * LP + (pg & 1) * 16) * 16 + rs[st];
                     xh[pg] = *reinterpret_cast<const bf16x8*>(&tile[base]);
                     xl[pg] = *reinterpret_cast<const bf16x8*>(&tile[KG == 1 ? (base ^ 8) : (base + PLANE)]);
@@ -481,11 +486,11 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                     const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wl[((st * MTW + mt) * 2 + 0) * 256 + lane * 4]);
                     const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&wl[((st * MTW + mt) * 2 + 1) * 256 + lane * 4]);
 #pragma unroll
-                    for (int pg = 0; pg < 4; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[pg], acc[pg][mt], 0, 0, 0);
+                    for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[pg], acc[pg][mt], 0, 0, 0);
 #pragma unroll
-                    for (int pg = 0; pg < 4; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[pg], acc[pg][mt], 0, 0, 0);
+                    for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[pg], acc[pg][mt], 0, 0, 0);
 #pragma unroll
-                    for (int pg = 0; pg < 4; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[pg], acc[pg][mt], 0, 0, 0);
+                    for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[pg], acc[pg][mt], 0, 0, 0);
                 }
             }
         } else {
@@ -494,10 +499,10 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
-                float xv[4][4];
+                float xv[PGW][4];
 #pragma unroll
-                for (int pg = 0; pg < 4; ++pg) {
-                    const int row = wave * 2 + (pg >> 1);
+                for (int pg = 0; pg < PGW; ++pg) {
+                    const int row = wave * RPW + (pg >> 1);
                     float4 v = ld4(&tile[g * PLANE + ((row + dy) * LP + (pg & 1) * 16) * 16 + rd[dx]]);
                     xv[pg][0] = v.x; xv[pg][1] = v.y; xv[pg][2] = v.z; xv[pg][3] = v.w;
                 }
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int pg = 0; pg < 4; ++pg)
+                        for (int pg = 0; pg < PGW; ++pg)
                             acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i], xv[pg][i], acc[pg][mt], 0, 0, 0);
                 }
             }
@@ -524,8 +529,8 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 rn_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rn + img, 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
         }
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg) {
-            const int row = wave * 2 + (pg >> 1), col = (pg & 1) * 16 + p;
+        for (int pg = 0; pg < PGW; ++pg) {
+            const int row = wave * RPW + (pg >> 1), col = (pg & 1) * 16 + p;
             const int gy = y0 + row, gx = x0 + col;
             const bool valid = gy < a.H && gx < a.W;
             float4 v[MTW];
@@ -624,10 +629,10 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         }
         if (EPI == EPI_TO_IMAGE) {
             // one tanh per lane instead of four: lane group q finishes pixel group q (same tanhf as the standalone ToImage kernel)
-            const int row = wave * 2 + (q >> 1), col = (q & 1) * 16 + p;
+            const int row = wave * RPW + (q >> 1), col = (q & 1) * 16 + p;
             const int gy = y0 + row, gx = x0 + col;
             const float tv = tanhf(timg);
-            if (gy < a.H && gx < a.W) a.aout[img + (long)gy * a.W + gx] = tv;
+            if (q < PGW && gy < a.H && gx < a.W) a.aout[img + (long)gy * a.W + gx] = tv;
         }
         t = tn;
     }
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 int launch_persist(ConvArgs a, hipStream_t s) {
     a.tiles_x = ngan::ceil_div(a.W, 32);
-    a.tiles_y = ngan::ceil_div(a.H, 8);
+    a.tiles_y = ngan::ceil_div(a.H, persist_tile_h(MTW, KG));
     const int n_tiles = a.B * a.tiles_x * a.tiles_y;
     // persistent grid = what is actually resident (registers and LDS both limit it): an over-subscribed static
     // tile partition would serialise whole workgroups behind each other
@@ -936,21 +941,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         const int tyi = t % a.tiles_y;
         const int b = t / a.tiles_y;
         const int y0 = tyi * TH, x0 = txi * TW;
-        const float* gb = a.g + (long)b * a.H * a.W * a.N;
+        // loads through per-image buffer descriptors: 32-bit offsets, and an out-of-range offset (tile edge, conv padding, unused
+        // staging slot) reads zeros -- no branch around the load and no zero-filled registers (see conv3x3_persist_kernel)
+        constexpr unsigned OOB = 0xFFFFFFF0u;
+        const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g + (long)b * a.H * a.W * a.N), 0,
+                                                                                 (unsigned)(a.H * a.W * a.N) * 4u, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int gy = y0 + g_r[i], gx = x0 + g_c[i];
-            gst[i] = (gy < a.H && gx < a.W) ? ld4(gb + ((long)gy * a.W + gx) * a.N + g_ch[i]) : f4zero();
+            const unsigned off = (gy < a.H && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.N + g_ch[i]) * 4) : OOB;
+            gst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, off, 0, 0));
         }
         if (RES == NGAN_RESAMPLE_UP2) {
-            const float* xb = a.x + (long)b * h * w * a.K;
+            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * h * w * a.K), 0,
+                                                                                     (unsigned)(h * w * a.K) * 4u, 0x00020000);
             const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
 #pragma unroll
             for (int i = 0; i < NXL; ++i) {
                 const int e = tid + i * 256;
                 const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
                 const int ly = min(max(ly0 + pix / PW, 0), h - 1), lx = min(max(lx0 + pix % PW, 0), w - 1);
-                xst[i] = e < NPI ? ld4(xb + ((long)ly * w + lx) * a.K + ci0 + c4 * 4) : f4zero();
+                const unsigned off = e < NPI ? (unsigned)(((ly * w + lx) * a.K + ci0 + c4 * 4) * 4) : OOB;
+                xst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+            }
+        } else if (RES == NGAN_RESAMPLE_NONE) {
+            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.H * a.W * a.K), 0,
+                                                                                     (unsigned)(a.H * a.W * a.K) * 4u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) {
+                const int gy = y0 + x_r[i], gx = x0 + x_c[i];        // x_r = -1000 marks an unused slot: fails the range test
+                const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.K + x_ch[i]) * 4) : OOB;
+                xst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
             }
         } else {
 #pragma unroll
@@ -1429,6 +1451,8 @@ extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, flo
     hipStream_t s = (hipStream_t)stream;
     int st;
     NGAN_REQUIRE(precision == 0 || precision == 1, NGAN_ERR_ARG, "conv3x3_wgrad: precision %d", precision);
+    NGAN_REQUIRE(precision == 0 || (long)H * W * (Cin > Cout ? Cin : Cout) * 16 < (1L << 32), NGAN_ERR_SHAPE,
+                 "conv3x3_wgrad: one image must stay below 1 GiB (H=%d W=%d): the split-bf16 kernel uses 32-bit byte offsets", H, W);
     if (p.co_s == 32 && p.ci_s == 32) st = launch_wgrad<2, 2>(a, p, resample, precision, s);
     else if (p.co_s == 32) st = launch_wgrad<2, 1>(a, p, resample, precision, s);
     else if (p.ci_s == 32) st = launch_wgrad<1, 2>(a, p, resample, precision, s);
