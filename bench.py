@@ -147,6 +147,8 @@ def main():
     torch.cuda.set_device(device)
     use_dist = world > 1 or args.force_dist
     if use_dist:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)          # `python bench.py --force-dist` without a launcher: a one-rank group
         if rehearsal:
             dist.init_process_group(rehearsal)
         else:

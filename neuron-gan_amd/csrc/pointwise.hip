@@ -106,27 +106,25 @@ __device__ __forceinline__ float load_img(const float* __restrict__ x, int b, in
     return 0.25f * ((p[0] + p[Ncol]) + (p[W2 * Ncol] + p[W2 * Ncol + Ncol]));
 }
 
+// one thread per (pixel, channel quad); blockIdx.y = image row (b*H + y), so no per-item division by W or H
 template <int POOL>
 __global__ __launch_bounds__(256) void from_image_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              int B, int H, int W, int Ncol, int C) {
     const unsigned Q = C / 4;
-    const unsigned total = (unsigned)B * H * W * Q;       // host checks that this fits 31 bits
-    for (unsigned gid = blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += gridDim.x * blockDim.x) {
-        const unsigned pix = gid / Q;
-        const int c0 = (int)(gid - pix * Q) * 4;
-        const unsigned row = pix / (unsigned)W;
-        const int xx = (int)(pix - row * W);
-        const int b = (int)(row / (unsigned)H);
-        const int yy = (int)(row - (unsigned)b * H);
-        float4 o = bias ? ld4(bias + c0) : f4zero();
-        for (int k = 0; k < Ncol; ++k) {
-            const float v = load_img<POOL>(x, b, yy, xx, k, H, W, Ncol);
-            o.x = fmaf(w[(c0 + 0) * Ncol + k], v, o.x); o.y = fmaf(w[(c0 + 1) * Ncol + k], v, o.y);
-            o.z = fmaf(w[(c0 + 2) * Ncol + k], v, o.z); o.w = fmaf(w[(c0 + 3) * Ncol + k], v, o.w);
-        }
-        st4(y + (long)pix * C + c0, o);
+    const unsigned it = blockIdx.x * 256 + threadIdx.x;        // item inside the row: xx * Q + channel quad
+    if (it >= (unsigned)W * Q) return;
+    const int xx = (int)(it / Q);
+    const int c0 = (int)(it - (unsigned)xx * Q) * 4;
+    const int row = blockIdx.y;
+    const int b = row / H, yy = row - b * H;
+    float4 o = bias ? ld4(bias + c0) : f4zero();
+    for (int k = 0; k < Ncol; ++k) {
+        const float v = load_img<POOL>(x, b, yy, xx, k, H, W, Ncol);
+        o.x = fmaf(w[(c0 + 0) * Ncol + k], v, o.x); o.y = fmaf(w[(c0 + 1) * Ncol + k], v, o.y);
+        o.z = fmaf(w[(c0 + 2) * Ncol + k], v, o.z); o.w = fmaf(w[(c0 + 3) * Ncol + k], v, o.w);
     }
+    st4(y + ((long)row * W + xx) * C + c0, o);
 }
 
 template <int Q, int POOL>
@@ -163,37 +161,40 @@ __global__ __launch_bounds__(256) void from_image_dx_kernel(const float* __restr
 // partial slab per block: [c*Ncol + k] for k < Ncol, then [C*Ncol + c] for the bias sums
 template <int Q, int POOL>
 __global__ __launch_bounds__(256) void from_image_dw_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                            float* __restrict__ partial, int B, int H, int W, int Ncol, int C) {
+                                                            float* __restrict__ partial, int B, int H, int W, int Ncol, int C,
+                                                            int rows_per_block) {
     __shared__ float4 red[256];
     const int tid = threadIdx.x, sub = tid % Q;
-    const unsigned npix = (unsigned)B * H * W;            // host checks that npix fits 31 bits
-    const unsigned stride = gridDim.x * (256 / Q);
+    // block = ROWS_PER_BLOCK consecutive image rows (b*H + y); a thread owns a fixed (column phase, channel quad) and walks the
+    // columns of each row with stride 256/Q: no division by W or H per item, four pixels in flight per iteration
+    const int rows = B * H;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+    constexpr int PPB = 256 / Q;                          // pixels per block-iteration
     float4 acc[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) acc[k] = f4zero();
-    // 4 pixels per iteration with every load issued before the first use: the loop is a latency chain otherwise
-    for (unsigned pix0 = blockIdx.x * (256 / Q) + tid / Q; pix0 < npix; pix0 += 4 * stride) {
-        float4 gv[4];
-        float xv[4][4];
+    for (int row = r0; row < r1; ++row) {
+        const int b = row / H, yy = row - b * H;
+        const float* grow = g + (long)row * W * C + sub * 4;
+        for (int x0 = tid / Q; x0 < W; x0 += 4 * PPB) {
+            float4 gv[4];
+            float xv[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned pu = pix0 + u * stride;
-            const unsigned pix = pu < npix ? pu : npix - 1;
-            gv[u] = ld4(g + (long)pix * C + sub * 4);
-            const unsigned row = pix / (unsigned)W;
-            const int xx = (int)(pix - row * W);
-            const int b = (int)(row / (unsigned)H);
-            const int yy = (int)(row - (unsigned)b * H);
+            for (int u = 0; u < 4; ++u) {
+                const int xu = x0 + u * PPB;
+                const int xx = xu < W ? xu : W - 1;
+                gv[u] = ld4(grow + (long)xx * C);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xv[u][k] = k < Ncol ? load_img<POOL>(x, b, yy, xx, k, H, W, Ncol) : 0.f;
-        }
+                for (int k = 0; k < 4; ++k) xv[u][k] = k < Ncol ? load_img<POOL>(x, b, yy, xx, k, H, W, Ncol) : 0.f;
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (pix0 + u * stride >= npix) gv[u] = f4zero();
-            acc[4] = f4add(acc[4], gv[u]);
+            for (int u = 0; u < 4; ++u) {
+                if (x0 + u * PPB >= W) gv[u] = f4zero();
+                acc[4] = f4add(acc[4], gv[u]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < Ncol) acc[k] = f4fma(gv[u], xv[u][k], acc[k]);
+                for (int k = 0; k < 4; ++k)
+                    if (k < Ncol) acc[k] = f4fma(gv[u], xv[u][k], acc[k]);
+            }
         }
     }
     float* slab = partial + (long)blockIdx.x * C * (Ncol + 1);
@@ -545,9 +546,10 @@ extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* 
                  "from_image_fwd: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
     NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_fwd: B*H*W*C/4 must be below 2^31");
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = ew_blocks((long)B * H * W * (C / 4));
-    if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<1>), dim3(nblk), dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
-    else hipLaunchKernelGGL((from_image_fwd_kernel<0>), dim3(nblk), dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    NGAN_REQUIRE((long)B * H < 65536, NGAN_ERR_SHAPE, "from_image_fwd: B*H must be below 65536");
+    const dim3 grid(ceil_div((long)W * (C / 4), 256), B * H);
+    if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<1>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    else hipLaunchKernelGGL((from_image_fwd_kernel<0>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
     return ngan::launch_status("ngan_from_image_fwd");
 }
 
@@ -574,10 +576,13 @@ extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, flo
                  "from_image_dw: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
     NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_dw: B*H*W*C/4 must be below 2^31");
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = stream_blocks((long)B * H * W, C / 4);
-#define CALL(QV)                                                                                                              \
-    if (pool) hipLaunchKernelGGL((from_image_dw_kernel<QV, 1>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C); \
-    else hipLaunchKernelGGL((from_image_dw_kernel<QV, 0>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C)
+    const int rows = B * H;
+    const int rpb_min = ceil_div(rows, MAX_PARTS), rpb_pref = rows >= 2048 ? 4 : 1;
+    const int rpb = rpb_min > rpb_pref ? rpb_min : rpb_pref;
+    const int nblk = ceil_div(rows, rpb);                 // <= MAX_PARTS slabs (the callers' workspace holds 1024)
+#define CALL(QV)                                                                                                                   \
+    if (pool) hipLaunchKernelGGL((from_image_dw_kernel<QV, 1>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C, rpb); \
+    else hipLaunchKernelGGL((from_image_dw_kernel<QV, 0>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C, rpb)
     Q_DISPATCH(CALL)
 #undef CALL
     int st = ngan::launch_status("ngan_from_image_dw");
