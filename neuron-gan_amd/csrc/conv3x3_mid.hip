@@ -56,15 +56,24 @@ struct MidCfg {
     static_assert(WP * PGW == 4, "a workgroup covers 4 pixel groups (4 rows x 16 pixels)");
 };
 
-template <int KG, int PGW, int MTW, int WN, int EPI, int OUTMODE>
-__global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resample) {
+// KS = 2: the contraction steps are dealt to two groups of 4 waves (512 threads per workgroup) and the two partial accumulators
+// are exchanged through LDS.  With one 4-wave workgroup per CU (all these layers offer) every SIMD hosts ONE wave, whose staging
+// VALU, MFMAs and waits simply add up (PMC: 27 % + 24 % + 38 % of the wave's lifetime); two waves per SIMD overlap them and each
+// has half the serial chain.
+template <int KG, int PGW, int MTW, int WN, int EPI, int OUTMODE, int KS>
+__global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int resample) {
     using C = MidCfg<KG, PGW, MTW, WN>;
-    constexpr int K = C::K, PITCH = C::PITCH, NPIX = C::NPIX, NSTEP = C::NSTEP, D = C::D;
+    constexpr int K = C::K, PITCH = C::PITCH, NPIX = C::NPIX, NSTEP = C::NSTEP, D = C::D, NT = 256 * KS;
+    static_assert(NSTEP % KS == 0, "the contraction steps must split evenly");
+    constexpr int OWN = NSTEP / KS;                                     // steps of one wave group
     constexpr int SS_BYTES = (EPI != EPI_NONE && WN > 1) ? WN * 4 * 16 * 4 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NPIX * PITCH + SS_BYTES];
-    float* ss_l = reinterpret_cast<float*>(smem + NPIX * PITCH);
+    constexpr int XCH_BYTES = KS > 1 ? 4 * KS * PGW * MTW * 1024 : 0;   // accumulator exchange (re-uses the tile region)
+    constexpr int TILE_BYTES = NPIX * PITCH > XCH_BYTES ? NPIX * PITCH : XCH_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES + SS_BYTES];
+    float* ss_l = reinterpret_cast<float*>(smem + TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave % WN, wp = wave / WN;
+    const int kh = wave >> 2, w4 = wave & 3;                            // wave group (contraction half), wave inside the group
+    const int wn = w4 % WN, wp = w4 / WN;
     const int p = lane & 15, q = lane >> 4;
     int t = blockIdx.x;
     const int txi = t % a.tiles_x; t /= a.tiles_x;
@@ -73,35 +82,47 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
     const int y0 = tyi * 4, x0 = txi * 16;
     const int MT = a.N >> 4;
     const int mt0 = blockIdx.y * (C::NS / 16) + wn * MTW;      // this wave's first 16-channel output tile
+    constexpr unsigned OOB = 0xFFFFFFF0u;
 
-    // ---- weight stream: fragment (step, mt, part) is 64 lanes x 16 B at bf16x8 index ((step*MT + mt)*2 + part)*64 + lane ----
-    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(a.wp) + (long)mt0 * 128 + lane;
+    // ---- weight stream: fragment (step, mt, part) is 64 lanes x 16 B at byte ((step*MT + mt)*2 + part)*1024 + lane*16.  Buffer
+    // loads: the lane part is a constant voffset, the (step, mt, part) part a scalar offset -- no per-load vector address math ----
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (unsigned)(9 * K * a.N) * 4u, 0x00020000);
+    const unsigned w_voff = (unsigned)(mt0 * 2048 + lane * 16);
     bf16x8 wr[D + 1][MTW][2];
-    auto wload = [&](int slot, int step) {
+    auto wload = [&](int slot, int own_step) {
+        const int step = own_step * KS + kh;                            // wave group kh takes steps kh, kh + KS, ...
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            wr[slot][mt][0] = wfrag[((long)step * MT + mt) * 128];
-            wr[slot][mt][1] = wfrag[((long)step * MT + mt) * 128 + 64];
+            const int soff = (step * MT + mt) * 2048;
+            wr[slot][mt][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, soff, 0));
+            wr[slot][mt][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, soff + 1024, 0));
         }
     };
 #pragma unroll
-    for (int s = 0; s < D && s < NSTEP; ++s) wload(s, s);
+    for (int s = 0; s < D && s < OWN; ++s) wload(s, s);
 
-    // ---- stage the halo tile, split into bf16 hi / lo.  Branch-free: every load is issued from a clamped (always valid)
-    // address and zeroed afterwards if it is conv padding, so all of a thread's loads are in flight together ----
-    constexpr int CQ = K / 4, NITEM = NPIX * CQ, NST = (NITEM + 255) / 256;
+    // ---- stage the halo tile, split into bf16 hi / lo.  Branch-free: plain input through a buffer descriptor of the image (an
+    // out-of-range offset = conv padding / unused slot reads zeros); resampled input from a clamped address, zeroed afterwards ----
+    constexpr int CQ = K / 4, NITEM = NPIX * CQ, NST = (NITEM + NT - 1) / NT;
     float4 stg[NST];
     auto stage = [&](auto res_tag) {
         constexpr int RES = decltype(res_tag)::value;
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.H * a.W * K), 0,
+                                                                                 (unsigned)(a.H * a.W * K) * 4u, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NT;
             const int pix = e / CQ, c4 = e % CQ;
             const int ty = pix / 18, tx = pix - ty * 18;
             const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-            const bool ok = e < NITEM && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-            stg[i] = f4select(ok, load_inside<RES>(a.x, b, cy, cx, c4 * 4, a.H, a.W, K));
+            const bool ok = e < NITEM && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            if (RES == NGAN_RESAMPLE_NONE) {
+                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * K + c4 * 4) * 4) : OOB;
+                stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+            } else {
+                const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+                stg[i] = f4select(ok, load_inside<RES>(a.x, b, cy, cx, c4 * 4, a.H, a.W, K));
+            }
         }
     };
     if (resample == NGAN_RESAMPLE_NONE) stage(std::integral_constant<int, NGAN_RESAMPLE_NONE>());
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
     else stage(std::integral_constant<int, NGAN_RESAMPLE_UP2>());
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-        const int e = tid + i * 256;
+        const int e = tid + i * NT;
         if (e < NITEM) {
             const int pix = e / CQ, c4 = e % CQ;
             const float4 v = stg[i];
@@ -133,7 +154,8 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
     // this lane's B-operand base: pixel (wp*PGW, p), channel octet q
     const unsigned char* xb = smem + ((wp * PGW) * 18 + p) * PITCH + q * 16;
     bf16x8 xh[2][PGW], xl[2][PGW];      // B operands, read from LDS one step ahead of their MFMAs
-    auto xload = [&](int slot, int step) {
+    auto xload = [&](int slot, int own_step) {
+        const int step = own_step * KS + kh;
         const int kg = step / 9, tap = step % 9, dy = tap / 3, dx = tap % 3;
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg) {
@@ -144,9 +166,9 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
     };
     xload(0, 0);
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-        if (s + D < NSTEP) wload((s + D) % (D + 1), s + D);
-        if (s + 1 < NSTEP) xload((s + 1) & 1, s + 1);
+    for (int s = 0; s < OWN; ++s) {
+        if (s + D < OWN) wload((s + D) % (D + 1), s + D);
+        if (s + 1 < OWN) xload((s + 1) & 1, s + 1);
         // keep the prefetches HERE: left alone, the machine scheduler sinks every weight load to just above its first use
         // (shorter live ranges) and the loop then pays one full L2 round trip per fragment (measured: 30 us instead of 8)
         __builtin_amdgcn_sched_barrier(0);
@@ -162,6 +184,25 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (KS > 1) {
+        // both wave groups end with the full sum (group 0 + group 1, the same order in both), so the epilogue below -- including
+        // its workgroup barriers -- runs unchanged on all waves; only group 0 stores
+        __syncthreads();                                               // every wave is done reading the tile
+        f32x4* xch = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) xch[((wave * PGW + pg) * MTW + mt) * 64 + lane] = acc[pg][mt];
+        __syncthreads();
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const f32x4 a0 = xch[((w4 * PGW + pg) * MTW + mt) * 64 + lane], a1 = xch[(((4 + w4) * PGW + pg) * MTW + mt) * 64 + lane];
+                acc[pg][mt] = a0 + a1;
+            }
+    }
+    const bool storing = kh == 0;
 
     // ---- epilogue: lane holds channels (mt0 + mt)*16 + 4q + {0..3} of pixel (y0 + wp*PGW + pg, x0 + p) ----
     float4 bv[MTW];
@@ -182,7 +223,7 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
         }
         if (WN > 1) {
             __syncthreads();           // ss_l may still be read from a previous call
-            if (q == 0) {
+            if (q == 0 && storing) {
 #pragma unroll
                 for (int pg = 0; pg < PGW; ++pg) ss_l[(wn * 4 + wp * PGW + pg) * 16 + p] = part[pg];
             }
@@ -220,7 +261,7 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
             const float inv = 1.0f / r;
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) v[pg][mt] = f4scale(v[pg][mt], inv);
-            if (gy < a.H && gx < a.W && q == 0 && wn == 0) a.rn[((long)b * a.H + gy) * a.W + gx] = r;
+            if (storing && gy < a.H && gx < a.W && q == 0 && wn == 0) a.rn[((long)b * a.H + gy) * a.W + gx] = r;
         }
     }
     const int ch0 = mt0 * 16 + q * 4;
@@ -255,7 +296,7 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
         }
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg)
-            if (valid[pg]) {
+            if (storing && valid[pg]) {
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) st4(a.y + pix[pg] * a.N + ch0 + mt * 16, v[pg][mt]);
             }
@@ -296,7 +337,7 @@ __global__ __launch_bounds__(256) void conv3x3_mid_kernel(ConvArgs a, int resamp
             }
 #pragma unroll
             for (int pg = 0; pg < PGW; ++pg)
-                if (valid[pg]) {
+                if (storing && valid[pg]) {
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt) st4(a.y + pix[pg] * a.N + ch0 + mt * 16, o4[pg][mt]);
                 }
@@ -317,12 +358,14 @@ int mid_slice(int n_tiles, int N) {
 
 template <int KG, int PGW, int MTW, int WN>
 int mid_launch_cfg(ConvArgs a, int n_tiles, int n_slices, int resample, int epi, int outmode, hipStream_t s) {
-    const dim3 grid(n_tiles, n_slices), block(256);
-    if (epi == EPI_PN_BWD && outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 1>), grid, block, 0, s, a, resample);
-    else if (epi == EPI_PN_BWD) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 0>), grid, block, 0, s, a, resample);
-    else if (outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 1>), grid, block, 0, s, a, resample);
-    else if (epi) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 1, 0>), grid, block, 0, s, a, resample);
-    else hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 0>), grid, block, 0, s, a, resample);
+    // split the contraction over two wave groups where it divides evenly and the accumulator exchange fits (N slices <= 64)
+    constexpr int KS = (KG % 2 == 0 && PGW * MTW <= 4) ? 2 : 1;
+    const dim3 grid(n_tiles, n_slices), block(256 * KS);
+    if (epi == EPI_PN_BWD && outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 1, KS>), grid, block, 0, s, a, resample);
+    else if (epi == EPI_PN_BWD) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 0, KS>), grid, block, 0, s, a, resample);
+    else if (outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 1, KS>), grid, block, 0, s, a, resample);
+    else if (epi) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 1, 0, KS>), grid, block, 0, s, a, resample);
+    else hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 0, KS>), grid, block, 0, s, a, resample);
     return ngan::launch_status("ngan_conv3x3_fwd(mid)");
 }
 
@@ -370,7 +413,8 @@ int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int
     const int ns = mid_slice(n_tiles, N);
     const int epi = ns == N ? epilogue : 0;
     const int pgw = ns == 128 ? 4 : 2, mtw = ns == 32 ? 1 : 2, wnn = ns == 128 ? 4 : 2;
-    snprintf(buf, len, "conv3x3_mid_kernel<%d, %d, %d, %d, %d, %d>", K / 32, pgw, mtw, wnn, epi, out_mode ? 1 : 0);
+    const int ks = ((K / 32) % 2 == 0 && pgw * mtw <= 4) ? 2 : 1;
+    snprintf(buf, len, "conv3x3_mid_kernel<%d, %d, %d, %d, %d, %d, %d>", K / 32, pgw, mtw, wnn, epi, out_mode ? 1 : 0, ks);
     return NGAN_OK;
 }
 
