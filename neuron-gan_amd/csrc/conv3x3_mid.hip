@@ -358,8 +358,8 @@ int mid_slice(int n_tiles, int N) {
 
 template <int KG, int PGW, int MTW, int WN>
 int mid_launch_cfg(ConvArgs a, int n_tiles, int n_slices, int resample, int epi, int outmode, hipStream_t s) {
-    // split the contraction over two wave groups where it divides evenly and the accumulator exchange fits (N slices <= 64)
-    constexpr int KS = (KG % 2 == 0 && PGW * MTW <= 4) ? 2 : 1;
+    constexpr int KS = 1;   // KS = 2 (instantiable where KG is even and PGW*MTW <= 4) measured equal within noise in graph replay and
+                            // 0-40 % slower per launch under rocprofv3: the weight stream, not the per-wave chain, bounds these launches
     const dim3 grid(n_tiles, n_slices), block(256 * KS);
     if (epi == EPI_PN_BWD && outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 1, KS>), grid, block, 0, s, a, resample);
     else if (epi == EPI_PN_BWD) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 0, KS>), grid, block, 0, s, a, resample);
@@ -413,7 +413,7 @@ int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int
     const int ns = mid_slice(n_tiles, N);
     const int epi = ns == N ? epilogue : 0;
     const int pgw = ns == 128 ? 4 : 2, mtw = ns == 32 ? 1 : 2, wnn = ns == 128 ? 4 : 2;
-    const int ks = ((K / 32) % 2 == 0 && pgw * mtw <= 4) ? 2 : 1;
+    const int ks = 1;
     snprintf(buf, len, "conv3x3_mid_kernel<%d, %d, %d, %d, %d, %d, %d>", K / 32, pgw, mtw, wnn, epi, out_mode ? 1 : 0, ks);
     return NGAN_OK;
 }
