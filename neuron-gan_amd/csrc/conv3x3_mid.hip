@@ -359,7 +359,9 @@ int mid_slice(int n_tiles, int N) {
 template <int KG, int PGW, int MTW, int WN>
 int mid_launch_cfg(ConvArgs a, int n_tiles, int n_slices, int resample, int epi, int outmode, hipStream_t s) {
     constexpr int KS = 1;   // KS = 2 (instantiable where KG is even and PGW*MTW <= 4) measured equal within noise in graph replay and
-                            // 0-40 % slower per launch under rocprofv3: the weight stream, not the per-wave chain, bounds these launches
+                            // 0-40 % slower per launch under rocprofv3.  Inside a replayed graph a 128->128 launch at 16x16 takes 6.6 us, 6.3 us
+                            // with the weight stream switched off (zero-record descriptor): neither the stream nor the wave chain is the limit;
+                            // what is left is one memory round trip of staging, ~2 us of MFMAs and the launch itself (tools/micro_graph.py)
     const dim3 grid(n_tiles, n_slices), block(256 * KS);
     if (epi == EPI_PN_BWD && outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 1, KS>), grid, block, 0, s, a, resample);
     else if (epi == EPI_PN_BWD) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 0, KS>), grid, block, 0, s, a, resample);
