@@ -183,6 +183,9 @@ int ngan_scale_rows(const float* g, const float* coef, float* out, int B, long n
 int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* y, float* rnorm, int B, int K, int S, int C,
                              float scale, float slope, float eps, void* stream);
 int ngan_linear_wgrad(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale, void* stream);
+/* accumulate != 0: gW += ... (K <= 512, a multiple of 16): adds straight into the parameter's gradient buffer */
+int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale, int accumulate,
+                          void* stream);
 int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream);
 
 /* ---- critic head: Conv2d_normalized(C, 1, (S,S), padding 0) + Flatten, models.py:485-490 ------------------------

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 // 16-byte store.  z (B x K) and gc are tiny and stay in L1/L2; the 4*C*S*K-byte result is written exactly once.
 template <int NT>
 __global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __restrict__ z, const float* __restrict__ gc,
-                                                                float* __restrict__ gW, int B, int K, int S, int C, float scale) {
+                                                                float* __restrict__ gW, int B, int K, int S, int C, float scale,
+                                                                int accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const long rows = (long)C * S;
@@ -163,7 +164,11 @@ __global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __r
         float* o = gW + row * K + kq * 4;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            if (t < nt) st4(o + t * 16, make_float4(acc[t][0] * scale, acc[t][1] * scale, acc[t][2] * scale, acc[t][3] * scale));
+            if (t < nt) {
+                float4 v = make_float4(acc[t][0] * scale, acc[t][1] * scale, acc[t][2] * scale, acc[t][3] * scale);
+                if (accumulate) v = f4add(v, ld4(o + t * 16));      // gW += ...: adds straight into the parameter's gradient buffer
+                st4(o + t * 16, v);
+            }
     }
 }
 
@@ -277,15 +282,24 @@ extern "C" int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* 
     return ngan::launch_status("ngan_linear_lrelu_pn_fwd");
 }
 
+extern "C" int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale,
+                                     int accumulate, void* stream);
+
 extern "C" int ngan_linear_wgrad(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale, void* stream) {
+    return ngan_linear_wgrad_acc(z, gc, gW, B, K, S, C, scale, 0, stream);
+}
+
+extern "C" int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale,
+                                     int accumulate, void* stream) {
     NGAN_REQUIRE(z && gc && gW, NGAN_ERR_ARG, "linear_wgrad: null pointer");
+    NGAN_REQUIRE(!accumulate || (K % 16 == 0 && K <= 512), NGAN_ERR_SHAPE, "linear_wgrad: accumulate needs K <= 512, a multiple of 16 (K=%d)", K);
     NGAN_REQUIRE(B > 0 && K > 0 && K % 4 == 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_wgrad: B=%d K=%d S=%d C=%d unsupported", B, K, S, C);
     NGAN_REQUIRE(K / 4 <= 256, NGAN_ERR_SHAPE, "linear_wgrad: K=%d must be at most 1024", K);
     const long rows = (long)C * S;
     if (K % 16 == 0 && K <= 512) {
         const dim3 grid(ngan::ceil_div(rows, 64)), block(256);
-        if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<8>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale);
-        else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<32>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale);
+        if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<8>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate);
+        else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<32>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate);
         return ngan::launch_status("ngan_linear_wgrad(mfma)");
     }
     const int rpb = rows >= 4096 ? 16 : 4;

@@ -849,6 +849,9 @@ class LinearLReLUPN(Function):
         if ctx.needs_input_grad[1]:
             if linear_grad_sink is not None:
                 linear_grad_sink(z, gc, weight, s2, c, scale)      # gradient is formed later from the gathered factors
+            elif _accumulates_in_place(weight) and k % 16 == 0 and k <= 512:
+                # weight.grad += ... inside the kernel: no 67 MB temporary and no separate 200 MB accumulate pass
+                _C.call("ngan_linear_wgrad_acc", z, gc, weight.grad, b, k, s2, c, float(scale), 1)
             else:
                 gw = torch.empty_like(weight)
                 _C.call("ngan_linear_wgrad", z, gc, gw, b, k, s2, c, float(scale))
