@@ -155,6 +155,7 @@ def small_fixture(models, name, res, alpha, warm_steps, batch=4, seed=11):
 # ------------------------------------------------------------------------------------------
 FULL = {  # name: (res, alpha, batch)
     "C1": (16, 1.0, 16), "C2": (64, 0.5, 64), "C3": (256, 1.0, 32), "C4": (512, 1.0, 16),
+    "C5": (512, 1.0, 8),      # BASELINE.json's fifth config (512x512, batch 8 per GPU); no SURVEY.md pin exists for it
 }
 SURVEY_PINS = {  # (D_loss, score_real, score_fake, GP, G_loss) recorded in SURVEY.md 8(c)
     "C1": (9.621342659, -0.006367247, -0.002287695, 9.617262840, 0.009899071),
@@ -214,10 +215,13 @@ def full_fixture(models, config, name):
     out.update(z_d=z_d.numpy(), z_gp=z_gp.numpy(), z_g=z_g.numpy(), eps=eps.numpy())
     out["real_cs"] = np.array([float(x.double().sum()), float(x.double().abs().sum())])
     out["meta"] = np.array([res, alpha, 16, 512, batch, 1e-4], dtype=np.float64)
-    pins = np.array(SURVEY_PINS[name])
-    rel = np.abs(out["scalars"] - pins) / np.abs(pins)
-    print(f"full_{name}: scalars={out['scalars']}  max rel diff vs SURVEY pins = {rel.max():.2e}")
-    assert rel.max() < 5e-6, "harness replay disagrees with the reference's own loss modules (SURVEY pins)"
+    if name in SURVEY_PINS:
+        pins = np.array(SURVEY_PINS[name])
+        rel = np.abs(out["scalars"] - pins) / np.abs(pins)
+        print(f"full_{name}: scalars={out['scalars']}  max rel diff vs SURVEY pins = {rel.max():.2e}")
+        assert rel.max() < 5e-6, "harness replay disagrees with the reference's own loss modules (SURVEY pins)"
+    else:
+        print(f"full_{name}: scalars={out['scalars']}  (same replay harness as the pinned configs; no SURVEY pin for this one)")
     np.savez_compressed(os.path.join(OUT, f"full_{name}.npz"), **out)
 
 
@@ -300,7 +304,7 @@ def main():
             small_fixture(models, name, res, alpha, warm)
     if not only or "checkpoint" in only:
         checkpoint_fixtures(models)
-    for name in (["C1", "C2"] + (["C3", "C4"] if args.full else [])):
+    for name in (["C1", "C2"] + (["C3", "C4", "C5"] if args.full else [])):
         if not only or name in only:
             full_fixture(models, config, name)
 
