@@ -43,8 +43,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // tap is zero padding), 5 steps.  K = 32*KG: step = kg*9 + tap covers input channels 32*kg .. 32*kg + 31 of one tap,
 // 9*KG steps (K = 32: a step is one tap; K = 64, 128: conv3x3_mid.hip).
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ packed, int Cout, int Cin,
-                                           int mode, float scale) {
-    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+                                           int mode, float scale, int pad32) {
+    // pad32 (precision 2): a K = 16 contraction laid out as K = 32 with zero weights for channels 16..31 (conv3x3_mid.hip)
+    const int Kreal = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    const int K = pad32 ? 32 : Kreal;
     const int MT = N / 16, nstep = K == 16 ? 5 : 9 * (K / 32);
     const long total = (long)nstep * MT * 2 * 64 * 8;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,7 +59,7 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, __bf16* 
     const int tap = K == 16 ? 2 * step + (kk >> 4) : step % 9;
     const int k = K == 16 ? (kk & 15) : (step / 9) * 32 + kk;
     float v = 0.f;
-    if (tap < 9) {
+    if (tap < 9 && k < Kreal) {
         if (mode == 0) v = w[((long)n * Cin + k) * 9 + tap];
         else           v = w[((long)k * Cin + n) * 9 + (8 - tap)];
     }
@@ -1171,7 +1173,8 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackEntry* __restr
     const PackEntry e = table[lo];
     const long idx = gidx - e.first;
     const int Cout = e.cout, Cin = e.cin, mode = e.mode;
-    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    const int Kreal = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    const int K = e.precision == 2 ? 32 : Kreal;
     if (e.precision == 0) {
         const int G = K / 16, MT = N / 16;
         const int i = idx & 3, lane = (idx >> 2) & 63;
@@ -1192,7 +1195,7 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackEntry* __restr
         const int tap = K == 16 ? 2 * step + (kk >> 4) : step % 9;
         const int k = K == 16 ? (kk & 15) : (step / 9) * 32 + kk;
         float v = 0.f;
-        if (tap < 9) v = mode == 0 ? e.src[((long)n * Cin + k) * 9 + tap] : e.src[((long)k * Cin + n) * 9 + (8 - tap)];
+        if (tap < 9 && k < Kreal) v = mode == 0 ? e.src[((long)n * Cin + k) * 9 + tap] : e.src[((long)k * Cin + n) * 9 + (8 - tap)];
         v *= e.scale;
         const __bf16 hi16 = (__bf16)v;
         reinterpret_cast<__bf16*>(e.dst)[idx] = part == 0 ? hi16 : (__bf16)(v - (float)hi16);
@@ -1208,7 +1211,9 @@ static long bf16x3_elements(int K, int N) {
 extern "C" long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int precision) {
     if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
     if (precision == 0) return 9L * Cin * Cout;
-    return mode == 0 ? bf16x3_elements(Cin, Cout) : bf16x3_elements(Cout, Cin);
+    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    if (precision == 2) return K == 16 ? bf16x3_elements(32, N) : 0;      // K = 16 padded to 32 (mid kernel)
+    return bf16x3_elements(K, N);
 }
 
 extern "C" int ngan_conv3x3_pack_many(const void* table, int n_entries, long total_elements, void* stream) {
@@ -1221,6 +1226,10 @@ extern "C" int ngan_conv3x3_pack_many(const void* table, int n_entries, long tot
 extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
     if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
     if (precision == 0) return 9L * Cin * Cout;
+    if (precision == 2) {
+        const long p0 = Cin == 16 ? bf16x3_elements(32, Cout) : 0, p1 = Cout == 16 ? bf16x3_elements(32, Cin) : 0;
+        return ((p0 > p1 ? p0 : p1) + 1) / 2;
+    }
     const long e0 = bf16x3_elements(Cin, Cout), e1 = bf16x3_elements(Cout, Cin);   // forward / flipped orientation
     return ((e0 > e1 ? e0 : e1) + 1) / 2;
 }
@@ -1228,7 +1237,10 @@ extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
 extern "C" int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision) {
     if (precision != 1 || B <= 0 || H <= 0 || W <= 0) return 0;
     if (persist_eligible(B, H, W, K, N, resample)) return 1;
-    return ngan::conv3x3_mid_eligible(B, H, W, K, N) ? 1 : 0;
+    if (ngan::conv3x3_mid_eligible(B, H, W, K, N)) return 1;
+    // K = 16 into 32..128 channels where the persistent kernel does not apply (pooled input, small images): the mid kernel with the
+    // contraction padded to 32 channels (zero weights) -- its own packed layout, hence its own precision code
+    return (K == 16 && ngan::conv3x3_mid_eligible(B, H, W, 32, N)) ? 2 : 0;
 }
 
 extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int Cin, int mode, float scale,
@@ -1237,13 +1249,14 @@ extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int
     NGAN_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_pack_weights: Cin=%d, Cout=%d must be positive multiples of 16", Cin, Cout);
     NGAN_REQUIRE(mode == 0 || mode == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: mode %d", mode);
-    NGAN_REQUIRE(precision == 0 || precision == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
-    if (precision == 1) {
+    NGAN_REQUIRE(precision >= 0 && precision <= 2, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
+    if (precision >= 1) {
         const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
-        const long tot = bf16x3_elements(K, N);
+        NGAN_REQUIRE(precision == 1 || K == 16, NGAN_ERR_SHAPE, "conv3x3_pack_weights: precision 2 is the K = 16 padded layout (K=%d)", K);
+        const long tot = precision == 2 ? bf16x3_elements(32, N) : bf16x3_elements(K, N);
         NGAN_REQUIRE(tot > 0, NGAN_ERR_SHAPE, "conv3x3_pack_weights: split-bf16 packing needs K = 16 or a multiple of 32 (K=%d, N=%d)", K, N);
         hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(ngan::ceil_div(tot, 256)), dim3(256), 0, (hipStream_t)stream,
-                           w_oihw, reinterpret_cast<__bf16*>(packed), Cout, Cin, mode, scale);
+                           w_oihw, reinterpret_cast<__bf16*>(packed), Cout, Cin, mode, scale, precision == 2 ? 1 : 0);
         return ngan::launch_status("ngan_conv3x3_pack_weights(bf16x3)");
     }
     const long total = 9L * Cin * Cout;
@@ -1258,7 +1271,7 @@ extern "C" int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, in
     const bool persist = persist_eligible(B, H, W, K, N, resample);
     if (epilogue == EPI_TO_IMAGE) return persist && resample == 0 && out_mode == 0 ? 1 : 0;
     if (epilogue == EPI_PN_BWD)
-        return (persist && resample == 0) || (precision == 1 && resample == 0 && ngan::conv3x3_mid_fuses_epilogue(B, H, W, K, N)) ? 1 : 0;
+        return (persist && resample == 0) || (precision >= 1 && resample == 0 && ngan::conv3x3_mid_fuses_epilogue(B, H, W, precision == 2 ? 32 : K, N)) ? 1 : 0;
     return 0;
 }
 
@@ -1267,7 +1280,7 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
                                    int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
                                    float slope, float eps, int precision, void* stream) {
     NGAN_REQUIRE(x && packed && (y || epilogue == EPI_TO_IMAGE), NGAN_ERR_ARG, "conv3x3_fwd: null pointer");
-    NGAN_REQUIRE(precision == 0 || (precision == 1 && ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, 1)), NGAN_ERR_ARG,
+    NGAN_REQUIRE(precision == 0 || precision == ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, 1), NGAN_ERR_ARG,
                  "conv3x3_fwd: precision %d is not available for this shape (ask ngan_conv3x3_uses_bf16x3)", precision);
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_fwd: bad dims B=%d H=%d W=%d", B, H, W);
     NGAN_REQUIRE(K > 0 && K % 16 == 0, NGAN_ERR_SHAPE, "conv3x3_fwd: K=%d must be a positive multiple of 16", K);
@@ -1294,7 +1307,7 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
         return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, precision, s)
                        : dispatch_persist<2, 2>(a, resample, epilogue, out_mode, precision, s);
     }
-    if (precision == 1)   // many channels, small image: split-bf16 kernel of conv3x3_mid.hip
+    if (precision >= 1)   // many channels, small image: split-bf16 kernel of conv3x3_mid.hip (precision 2: K = 16 padded to 32)
         return ngan::conv3x3_mid_launch(x, packed, bias, y, rnorm, aux_in, aux_rn, B, H, W, K, N, resample, epilogue, out_mode, slope, eps, s);
     // generic exact-fp32 kernel: it has epilogues 0 and 1; the PixelNorm backward runs as a second launch, in place
     const int epi = epilogue == EPI_PN_BWD ? EPI_NONE : epilogue;
@@ -1326,8 +1339,8 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0)
         snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
                  (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision);
-    else if (precision == 1 && ngan::conv3x3_mid_eligible(B, H, W, K, N))
-        return ngan::conv3x3_mid_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, buf, len);
+    else if (precision >= 1 && ngan::conv3x3_mid_eligible(B, H, W, precision == 2 ? 32 : K, N))
+        return ngan::conv3x3_mid_kernel_name(B, H, W, precision == 2 ? 32 : K, N, resample, epilogue, out_mode, buf, len);
     else {
         const TileCfg c = kCfg[mti][ci];
         snprintf(buf, len, "conv3x3_kernel<%d, %d, %d, %d, %d, %d, %d>", c.mtw, c.wn, c.pgw, c.pcg, out_mode ? 0 : resample,

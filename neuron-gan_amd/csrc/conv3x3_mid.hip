@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
 
     // ---- weight stream: fragment (step, mt, part) is 64 lanes x 16 B at byte ((step*MT + mt)*2 + part)*1024 + lane*16.  Buffer
     // loads: the lane part is a constant voffset, the (step, mt, part) part a scalar offset -- no per-load vector address math ----
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (unsigned)(9 * K * a.N) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (unsigned)(9 * K * a.N) * 4u, 0x00020000);   // K, not a.K: the packed layout
     const unsigned w_voff = (unsigned)(mt0 * 2048 + lane * 16);
     bf16x8 wr[D + 1][MTW][2];
     auto wload = [&](int slot, int own_step) {
@@ -107,21 +107,22 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
     float4 stg[NST];
     auto stage = [&](auto res_tag) {
         constexpr int RES = decltype(res_tag)::value;
-        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.H * a.W * K), 0,
-                                                                                 (unsigned)(a.H * a.W * K) * 4u, 0x00020000);
+        // a.K is the tensor's channel count; it is smaller than the kernel's K only for a 16-channel input padded to 32 (zeros)
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.H * a.W * a.K), 0,
+                                                                                 (unsigned)(a.H * a.W * a.K) * 4u, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int e = tid + i * NT;
             const int pix = e / CQ, c4 = e % CQ;
             const int ty = pix / 18, tx = pix - ty * 18;
             const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-            const bool ok = e < NITEM && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const bool ok = e < NITEM && c4 * 4 < a.K && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             if (RES == NGAN_RESAMPLE_NONE) {
-                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * K + c4 * 4) * 4) : OOB;
+                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.K + c4 * 4) * 4) : OOB;
                 stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
             } else {
                 const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-                stg[i] = f4select(ok, load_inside<RES>(a.x, b, cy, cx, c4 * 4, a.H, a.W, K));
+                stg[i] = f4select(ok, load_inside<RES>(a.x, b, cy, cx, min(c4 * 4, a.K - 4), a.H, a.W, a.K));
             }
         }
     };
@@ -400,7 +401,7 @@ int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, f
     const bool fused = epilogue == EPI_NONE || ns == N;      // the channel-reducing epilogues need all N channels in one workgroup
     const int epi = fused ? epilogue : EPI_NONE;
     int st;
-    if (K == 32) st = mid_launch_kg<1>(a, n_tiles, ns, resample, epi, out_mode, s);
+    if (K == 32 || K == 16) st = mid_launch_kg<1>(a, n_tiles, ns, resample, epi, out_mode, s);   // K = 16: padded weights, a.K = 16
     else if (K == 64) st = mid_launch_kg<2>(a, n_tiles, ns, resample, epi, out_mode, s);
     else st = mid_launch_kg<4>(a, n_tiles, ns, resample, epi, out_mode, s);
     if (st || fused) return st;
