@@ -7,8 +7,10 @@ A "step" is one full iteration of the reference's inner loop (train.py:357-385):
 penalty, backward, Adam) then G step (loss, backward, Adam), n_critic = 1, at the 512x512 final stage (alpha = 1),
 batch 16 per GPU, fp32, synthetic reals 2*U[0,1)-1 already resident in HBM and unit-sphere latents drawn on the GPU.
 Rank 0 prints ONE JSON line: images/s over all ranks, plus
-  roofline     -- the dominant kernel (the MFMA 3x3 conv) timed with HIP events on its launch stream during the timed
-                  steps: achieved = algorithmic flops of those launches / their summed duration; peak = fp32 MFMA 157.3 TF
+  roofline     -- the dominant kernel (the conv template instance with the largest summed time over ngan_conv3x3_fwd and
+                  ngan_conv3x3_fwd_ex) timed with HIP events on its launch stream: achieved = algorithmic bytes (split-bf16
+                  instances: HBM roof, 8 TB/s) or flops (exact-fp32 instances: fp32 MFMA roof, 157.3 TF) of those launches / their
+                  summed duration; traffic = HBM bytes per launch from the committed PMC summary (profiles/, tools/measure_round.sh)
   cpu_baseline -- the CPU oracle (oracle/pggan_oracle.py, a port of the reference's path) timed on this host's cores on a
                   bounded sample of the same workload (N = 1 only).
 """

@@ -12,15 +12,16 @@ Closure under differentiation (what the backward of each operator is built from)
     FromImage / FromImageDx / FromImageDw, FinalDot / FinalDotDx / FinalDotDw: bilinear triples, closed
     Lerp <-> FadeBwd, Up2 <-> Up2Adjoint, Pool2 <-> Pool2Adjoint: linear pairs
 """
+import os
+import struct
 import weakref
 
+import numpy as np
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _C
-
-import os
 
 RES_NONE, RES_POOL2, RES_UP2 = 0, 1, 2
 EPI_NONE, EPI_LRELU_PN, EPI_PN_BWD, EPI_TO_IMAGE = 0, 1, 2, 3      # epilogues of ngan_conv3x3_fwd_ex (include/ngan.h)
@@ -90,10 +91,6 @@ PIXELNORM_EPS = 1e-8  # models.py:105 of the reference
 # parameters through raw pointers) `bump_weight_epoch()` marks them stale and `refresh_packed()` re-packs all of them
 # with one table-driven launch.  Packed copies of other tensors (the "weights" of a double-backward) are one-shot.
 # ---------------------------------------------------------------------------------------------------------
-import struct
-
-import numpy as np
-
 _weight_epoch = 0
 _registry = {}          # key -> dict(ref, packed, cout, cin, mode, prec, scale, epoch)
 _table = None           # (device table tensor, n_entries, total_elements, registry size it was built for)
