@@ -77,3 +77,28 @@ def test_no_augmentation_is_crop_renormalise_resize(ngan):
     assert sizes == [2, 1]                                             # the reference iterator's short last batch
     with pytest.raises(IndexError):
         ds.batch([3])
+
+
+def test_epoch_driver_on_the_device_dataset(ngan):
+    """train.pggan_train fed by data.NeuronDataset: augmented batches at the stage's resolution across a growth event, an
+    adaptive critic schedule (reference utils.Calculate_D_steps) and the similarity-loss monitor switched on."""
+    import types
+
+    import numpy as np
+    models, train = ngan.models, ngan.train
+    cfg = types.SimpleNamespace(adapt_critic=True, sim_loss_lambda=0.5, sim_loss_lambda_decay_rate=0.1, n_critic=2, batch_size=4,
+                                transit_sch=[2], N_epochs=4, alpha_step=0.5, learning_rate=1e-3, checkpointing_period=100, ID="t002")
+    torch.manual_seed(6)
+    G = models.Generator_PG([32, 16], image_size_init=8, latent_dim=32).to("cuda:0")
+    D = models.Discriminator_PG([16, 32], image_size_init=8).to("cuda:0")
+    data = ngan.data.NeuronDataset(torch.rand(6, 1, 16, 16), augmentations=True, im_translation=0.1, device="cuda:0", seed=1,
+                                   noise_mean=[0.05] * 6, noise_std=[0.01] * 6)
+    seen = []
+    orig = data.batch
+    data.batch = lambda idx, params=None: (lambda out: (seen.append(tuple(out.shape)), out)[1])(orig(idx, params))
+    tr = train.PGGANTrainer(G, D, learning_rate=cfg.learning_rate, alpha_step=cfg.alpha_step, n_critic=cfg.n_critic, device_latents=True)
+    series = train.pggan_train(tr, data, cfg, log=lambda *_: None)
+    assert all(len(v) == 4 and np.isfinite(v).all() for v in series.values())
+    assert G.image_size == 16 and data.image_size == 16
+    assert (4, 1, 8, 8) in seen and (4, 1, 16, 16) in seen and (2, 1, 16, 16) in seen     # stage sizes and the short last batch
+    assert float(data.images.min()) > 0.0                                                   # noise fill replaced the zero padding
