@@ -88,7 +88,8 @@ PIXELNORM_EPS = 1e-8  # models.py:105 of the reference
 # packed weights.  A conv weight is used in MFMA-fragment order, pre-scaled, possibly split into bf16 hi/lo, and in a
 # forward and a flipped (dgrad) orientation.  Packed copies of PARAMETERS are persistent: one buffer per
 # (parameter, orientation, precision, scale), registered on first use; after an optimiser step (which updates the
-# parameters through raw pointers) `bump_weight_epoch()` marks them stale and `refresh_packed()` re-packs all of them
+# parameters through raw pointers) `refresh_packed(owner, params)` re-packs that optimiser's parameters (`bump_weight_epoch()` marks
+# every copy stale instead: precision switches, graph capture)
 # with one table-driven launch.  Packed copies of other tensors (the "weights" of a double-backward) are one-shot.
 # ---------------------------------------------------------------------------------------------------------
 _weight_epoch = 0
@@ -110,13 +111,20 @@ def clear_packed():
     bump_weight_epoch()
 
 
-def refresh_packed():
-    """Re-pack every registered parameter with ONE launch; returns the number of entries refreshed."""
+def refresh_packed(owner=None, params=None):
+    """Re-pack the registered packed copies with ONE launch; returns the number of entries refreshed.  With `params` (an iterable
+    of parameters) and `owner` (any hashable tag for that set, e.g. id of the optimiser) only the copies of those parameters are
+    re-packed -- after the critic's Adam step the generator's packed weights are still valid, and vice versa."""
     global _table
-    live = [e for e in _registry.values() if e["ref"]() is not None]
+    if _table is None or not isinstance(_table, dict):
+        _table = {}
+    ids = None if params is None else {id(p) for p in params}
+    live = [e for e in _registry.values() if e["ref"]() is not None and (ids is None or id(e["ref"]()) in ids)]
     if not live:
         return 0
-    if _table is None or _table[3] != len(live):
+    ptrs = [e["ref"]().data_ptr() for e in live]
+    cached = _table.get(owner)
+    if cached is None or cached[3] != len(live) or cached[4] != ptrs:
         rec, first = b"", 0
         for e in live:
             w = e["ref"]()
@@ -125,11 +133,8 @@ def refresh_packed():
             first += _C.lib().ngan_conv3x3_pack_elements(e["cout"], e["cin"], e["mode"], e["prec"])
         dev = live[0]["packed"].device
         table = torch.from_numpy(np.frombuffer(rec, dtype=np.uint8).copy()).to(dev)
-        _table = (table, len(live), first, len(live), [e["ref"]().data_ptr() for e in live])
-    elif _table[4] != [e["ref"]().data_ptr() for e in live]:
-        _table = None                      # a parameter was re-homed: rebuild
-        return refresh_packed()
-    _C.call("ngan_conv3x3_pack_many", _table[0], _table[1], _table[2])
+        cached = _table[owner] = (table, len(live), first, len(live), ptrs)
+    _C.call("ngan_conv3x3_pack_many", cached[0], cached[1], cached[2])
     for e in live:
         e["epoch"] = _weight_epoch
         e["version"] = e["ref"]()._version

@@ -110,8 +110,12 @@ class FusedAdam:
             self._push()
         _C.call("ngan_adam_step", f.flat, f.grad, f.exp_avg, f.exp_avg_sq, f.seg_off, f.seg_len, f.seg_active, f.seg_step,
                 len(f.params), f.chunk_seg, f.chunk_off, int(f.chunk_seg.numel()), self.hyper)
-        ops.bump_weight_epoch()  # packed conv weights are stale now ...
-        ops.refresh_packed()     # ... re-pack every registered one with a single launch
+        self.repack()
+
+    def repack(self):
+        """this net's packed conv weights are stale after a step: re-pack them (and only them -- the other net's copies are still
+        valid) with a single launch"""
+        ops.refresh_packed(owner=id(self), params=self.flat.params)
 
 
 def exchange_gradients(flat: FlatParams, world: int, group=None, force: bool = False):
@@ -269,6 +273,17 @@ class PGGANTrainer:
             return
         exchange_gradients(flat, self.world, self.group, force=self.force_exchange)
 
+    def _exchange_between_captures(self, flat):
+        """The exchange issued between two graph captures, fenced by host synchronisation on both sides: the previous segment's
+        capture is completely closed before the collective is enqueued and the collective is complete before the next capture
+        begins (replayed steps use the plain stream-ordered `_exchange`).  Together with the "thread_local" capture mode this keeps
+        the process group's watchdog thread (which polls collective events with hipEventQuery) out of the capture's way; an abort
+        with hipErrorCapturedEvent was seen once in ~15 runs of the unfenced version.  (Running this collective on a dedicated
+        stream instead was tried: replay then slowed down 20x in the two-rank gloo rehearsal.)"""
+        torch.cuda.synchronize()
+        self._exchange(flat)
+        torch.cuda.synchronize()
+
     def d_compute(self, real, z_d=None, z_gp=None, eps=None):
         """D half-step up to (and including) the backward pass: gradients end up in flat_d.grad."""
         b = real.size(0)
@@ -370,23 +385,35 @@ class PGGANTrainer:
                 self.train_iteration(self._static_real)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ops.bump_weight_epoch()   # the warm-up registered every packed weight (persistent buffers, allocated outside capture)
-        ops.refresh_packed()
+        ops.bump_weight_epoch()   # the warm-up registered every packed weight (persistent buffers, allocated outside capture):
+        self.opt_d.repack()       # rebuild both re-pack tables now, so that the captured Adam steps find them complete
+        self.opt_g.repack()
+        ops.refresh_packed()      # (copies of tensors that belong to neither optimiser)
+        # With a process group alive, its watchdog thread polls the events of earlier collectives (hipEventQuery) while a segment
+        # is being captured; in the default "global" capture mode HIP turns that into an error that kills the process
+        # (intermittently: it depends on whether the watchdog had already reaped the previous collective).  "thread_local" only
+        # polices the capturing thread.
+        mode = os.environ.get("NGAN_CAPTURE_MODE") or ("thread_local" if (dist.is_available() and dist.is_initialized()) else "global")
+        if segmented:
+            torch.cuda.synchronize()
+            if self.world > 1 or self.force_exchange:
+                dist.barrier(group=self.group)          # every rank's warm-up collectives are complete before the first capture
+                torch.cuda.synchronize()
         if not segmented:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=mode):
                 self._static_stats = self.train_iteration(self._static_real)
             self._graph = [graph]
         else:
             ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, capture_error_mode=mode):
                 stats = self.d_compute(self._static_real)
-            self._exchange(self.flat_d)
-            with torch.cuda.graph(gb, pool=ga.pool()):
+            self._exchange_between_captures(self.flat_d)
+            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=mode):
                 self.opt_d.step()
                 stats.update(self.g_compute(self._static_real))
-            self._exchange(self.flat_g)
-            with torch.cuda.graph(gc, pool=ga.pool()):
+            self._exchange_between_captures(self.flat_g)
+            with torch.cuda.graph(gc, pool=ga.pool(), capture_error_mode=mode):
                 self.opt_g.step()
             self._static_stats = stats
             self._graph = [ga, gb, gc]
