@@ -60,7 +60,10 @@ def first_order_enabled():
 
 class PNLink:
     """Hand-off between the LeakyReLU->PixelNorm that produced a tensor (y, rn) and the single conv consuming it.  The consumer's
-    backward sets `fused` after it has applied the producer's LeakyReLU->PixelNorm backward to the gradient it returns."""
+    backward sets `fused` after it has applied the producer's LeakyReLU->PixelNorm backward to the gradient it returns.
+    `y` / `rn` are DETACHED aliases of the producer's outputs: the producer's autograd node holds this object, and a reference to
+    its own outputs (which point back to the node) would be a cycle through C++ that neither refcounting nor gc can free --
+    every eager iteration would leak its activations (tools/leak_check.py)."""
     __slots__ = ("y", "rn", "slope", "fused")
 
     def __init__(self):
@@ -356,11 +359,11 @@ class ConvLReLUPN(Function):
         ctx.has_bias = bias is not None
         ctx.cfg = (resample, scale, slope)
         ctx.n_in = 6 + (in_link is not None or out_link is not None) * 2
-        if in_link is not None and in_link.y is not x:
+        if in_link is not None and (in_link.y.data_ptr() != x.data_ptr() or in_link.y.shape != x.shape):
             raise RuntimeError("PixelNorm hand-off: the conv's input is not the linked producer's output")
         ctx.in_link, ctx.out_link = in_link, out_link
         if out_link is not None:
-            out_link.y, out_link.rn, out_link.slope, out_link.fused = y, rn, slope, False
+            out_link.y, out_link.rn, out_link.slope, out_link.fused = y.detach(), rn.detach(), slope, False   # aliases without grad_fn
         ctx.stash = GradStash()
         return y, rn
 
@@ -412,7 +415,7 @@ class ConvLReLUPNToImage(Function):
             ctx.save_for_backward(x, weight, y, rn, t, w_img)
         ctx.has_bias = bias is not None
         ctx.cfg = (resample, scale, slope)
-        if in_link is not None and in_link.y is not x:
+        if in_link is not None and (in_link.y.data_ptr() != x.data_ptr() or in_link.y.shape != x.shape):
             raise RuntimeError("PixelNorm hand-off: the conv's input is not the linked producer's output")
         ctx.in_link = in_link
         return t
@@ -832,7 +835,7 @@ class LinearLReLUPN(Function):
         ctx.n_in = 5 + (out_link is not None)
         ctx.out_link = out_link
         if out_link is not None:
-            out_link.y, out_link.rn, out_link.slope, out_link.fused = y, rn, slope, False
+            out_link.y, out_link.rn, out_link.slope, out_link.fused = y.detach(), rn.detach(), slope, False   # aliases without grad_fn
         return y, rn
 
     @staticmethod

@@ -132,3 +132,21 @@ def test_stem_factor_exchange_matches_plain_gradient(ngan):
         out.append({k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+def test_eager_iterations_do_not_leak_device_memory(ngan):
+    """The first-order hand-off objects (ops.PNLink) are held by autograd nodes; they must not hold those nodes' own outputs (a
+    cycle through C++ that gc cannot break leaked every iteration's activations once).  Allocated memory must be flat."""
+    torch.manual_seed(2)
+    G = ngan.models.Generator_PG([32, 16, 16], image_size_init=8, latent_dim=32)
+    D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=8)
+    G.set_resolution(32, 1.0)
+    D.set_resolution(32, 1.0)
+    tr = ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), device_latents=True)
+    x = (torch.rand(4, 1, 32, 32) * 2 - 1).to(DEV)
+    seen = []
+    for i in range(8):
+        tr.train_iteration(x)
+        torch.cuda.synchronize()
+        seen.append(torch.cuda.memory_allocated())
+    assert seen[-1] <= seen[3], seen
