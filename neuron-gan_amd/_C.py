@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libngan_hip.so")
+LIB_PATH = os.environ.get("NGAN_LIB_PATH") or os.path.join(_HERE, "libngan_hip.so")      # (override: A/B runs of kernel variants)
 
 _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 
