@@ -208,6 +208,24 @@ int ngan_adam_step(float* p, const float* g, float* m, float* v, const long* seg
                    const int* seg_active, float* seg_step, int n_seg, const int* chunk_seg, const long* chunk_off,
                    int n_chunks, const float* hyper, void* stream);
 
+/* ---- the critic's first layer pair as one operator (first-order passes): FromImage (ONE colour channel, models.py:161-165) folded
+ * into the block's first 3x3 conv + LeakyReLU + PixelNorm (models.py:252-264).  f[c] = wf[c]*p + bf[c] is affine in one number per
+ * pixel, so the conv over its C channels is a 3x3 conv over ONE channel with A[n][t] = scale*sum_c W[n][c][t]*wf[c] and a
+ * border-aware bias sum_t Bv[n][t] (taps inside the image only); the C-channel tensor is never written.
+ *   p (B,H,W) image (already pooled);  w_conv (N,C,3,3), b_conv (N) or NULL;  wf, bf (C);  y (B,H,W,N), rnorm (B,H,W);
+ *   N in {16, 32}, C <= 64
+ *   bwd: gw_conv (+)= dL/dW, gwf, gbf, gb_conv (or NULL) from gc = dL/d(pre-activation);  workspace: ngan_first_block_workspace_floats floats
+ *   dx:  gx = dL/dp (pool = 0) or its avg-pool adjoint on the (B,2H,2W) image (pool = 1) */
+size_t ngan_first_block_table_floats(int N);      /* = 2*9*N: the folded tables A, Bv (written by fwd, read by dx) */
+int ngan_first_block_fwd(const float* p, const float* w_conv, const float* wf, const float* bf, const float* b_conv, float* y,
+                         float* rnorm, float* tables, int B, int H, int W, int C, int N, float scale, float slope, float eps,
+                         void* stream);
+size_t ngan_first_block_workspace_floats(int B, int H, int N);
+int ngan_first_block_bwd(const float* p, const float* gc, const float* w_conv, const float* wf, const float* bf,
+                         float* gw_conv, float* gwf, float* gbf, float* gb_conv, float* workspace, int B, int H, int W, int C,
+                         int N, float scale, int accumulate, void* stream);
+int ngan_first_block_dx(const float* gc, const float* tables, float* gx, int B, int H, int W, int N, int pool, void* stream);
+
 /* ---- on-device input pipeline: data/NeuronDataset.py:112-126, 149-164 (torchvision RandomAffine / RandomVerticalFlip /
  * ColorJitter / CenterCrop / Renormalize / Resize(antialias) per image) as two launches per batch, one colour channel.
  *   src     (N, P, P) padded images in [0, 1];  idx (B) int32: which image each sample uses

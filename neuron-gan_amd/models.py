@@ -599,9 +599,17 @@ class Discriminator_PG(_ProgressiveNet):
         """block(FromImage(x)) for a down-sampling block -> (output, its PNLink).  FromImage is affine per pixel and AvgPool2d is
         linear, so pool(FromImage(x)) == FromImage(pool(x)): the image is pooled while FromImage loads it and the block's first
         conv runs without resampling -- the C-channel tensor at the image's full resolution is never written."""
-        if _resample_of(block[0]) == ops.RES_POOL2:
-            return _exec(_plan(list(block)[1:]), from_im.nhwc(x, pool=True))
-        return _exec(_plan(block), from_im.nhwc(x))
+        pool = _resample_of(block[0]) == ops.RES_POOL2
+        steps = _plan(list(block)[1:] if pool else block)
+        first = steps[0]
+        if (ops.first_order_enabled() and first[0] == 'conv_lrelu_pn' and first[2] == ops.RES_NONE
+                and ops.first_block_fusable(x, from_im.conv.weight, first[1].weight)):
+            # differentiated once, one colour: FromImage folds into the conv (ops.FirstBlock), its output is never materialised
+            link = ops.PNLink() if torch.is_grad_enabled() else None
+            y, _ = ops.FirstBlock.apply(x, from_im.conv.weight, from_im.conv.bias, first[1].weight, first[1].bias, pool,
+                                        first[1].scale_value, first[3], link)
+            return _exec(steps[1:], y, link)
+        return _exec(steps, from_im.nhwc(x, pool=pool))
 
     def _merge_pending_block(self):
         self.layers.insert(0, self.conv_block_list.pop(-1))

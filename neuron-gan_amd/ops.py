@@ -637,6 +637,68 @@ class FromImage(Function):
         return gx, gw, gb, None
 
 
+_first_block_allowed = os.environ.get("NGAN_FIRST_BLOCK", "1") != "0"      # A/B switch for measurements
+
+
+def first_block_fusable(x, w_from, w_conv):
+    """can FirstBlock take FromImage -> conv3x3 -> LeakyReLU -> PixelNorm?  (one colour channel, 16 or 32 conv outputs)"""
+    return (_first_block_allowed and x.shape[-1] == 1 and w_from.shape[1] == 1 and w_conv.shape[0] in (16, 32)
+            and w_conv.shape[1] <= 64 and x.shape[0] * x.shape[1] < 65536)
+
+
+class FirstBlock(Function):
+    """(y, rnorm) = PixelNorm(LeakyReLU(conv3x3(FromImage(pool?(x)), scale*W) + b)) for a ONE-colour image, first order only:
+    FromImage's output is affine in the pixel value, so the pair collapses to a 3x3 conv over one channel whose tables are built
+    in the kernel (csrc/first_block.hip); the C-channel tensor between the two layers never exists, and the weight gradients of
+    both layers come from two 9 x N tables of pixel sums."""
+
+    @staticmethod
+    def forward(ctx, x, w_from, b_from, weight, bias, pool, scale, slope, out_link=None):
+        x = _c(x)
+        b, h, wd = _from_image_out_hw(x, pool)
+        n, c = weight.shape[0], weight.shape[1]
+        p = _resample("ngan_pool2_fwd", x, (b, h, wd, 1), b, h, wd, 1) if pool else x
+        y = torch.empty((b, h, wd, n), device=x.device, dtype=torch.float32)
+        rn = torch.empty((b, h, wd), device=x.device, dtype=torch.float32)
+        tables = torch.empty(2 * 9 * n, device=x.device, dtype=torch.float32)
+        _C.call("ngan_first_block_fwd", p, weight.detach(), w_from.detach().reshape(c), b_from, bias, y, rn, tables, b, h, wd, c, n,
+                float(scale), float(slope), PIXELNORM_EPS)
+        ctx.save_for_backward(p, w_from, b_from, weight, y, rn, tables)
+        ctx.cfg = (pool, scale, slope, bias is not None)
+        ctx.out_link = out_link
+        if out_link is not None:
+            out_link.y, out_link.rn, out_link.slope, out_link.fused = y.detach(), rn.detach(), slope, False
+        ctx.mark_non_differentiable(rn)
+        return y, rn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, gr):
+        p, w_from, b_from, weight, y, rn, tables = ctx.saved_tensors
+        pool, scale, slope, has_bias = ctx.cfg
+        b, h, wd, n = y.shape
+        c = weight.shape[1]
+        if ctx.out_link is not None and ctx.out_link.fused:
+            gc = _c(gy)         # the consumer's input-gradient kernel already applied this layer's LeakyReLU->PixelNorm backward
+        else:
+            gc = torch.empty_like(y)
+            _C.call("ngan_lrelu_pixelnorm_bwd", _c(gy), None, y, rn, gc, y.numel() // n, n, float(slope))
+        dev = y.device
+        ws = torch.empty(_C.lib().ngan_first_block_workspace_floats(b, h, n), device=dev, dtype=torch.float32)
+        in_place = ctx.needs_input_grad[3] and _accumulates_in_place(weight)
+        gw = weight.grad if in_place else torch.empty_like(weight)
+        gwf = torch.empty_like(w_from)
+        gbf = torch.empty_like(b_from) if b_from is not None else None
+        gb = torch.empty(n, device=dev, dtype=torch.float32) if has_bias else None
+        _C.call("ngan_first_block_bwd", p, gc, weight.detach(), w_from.detach().reshape(c), b_from, gw, gwf, gbf, gb, ws,
+                b, h, wd, c, n, float(scale), 1 if in_place else 0)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((b, 2 * h, 2 * wd, 1) if pool else (b, h, wd, 1), device=dev, dtype=torch.float32)
+            _C.call("ngan_first_block_dx", gc, tables, gx, b, h, wd, n, int(pool))
+        return gx, gwf, gbf, (None if in_place else gw), gb, None, None, None, None
+
+
 class FromImageDx(Function):
     @staticmethod
     def forward(ctx, g, w, pool):

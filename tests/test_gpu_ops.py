@@ -194,6 +194,113 @@ def test_pixelnorm_handoff_matches_unfused(ngan, case, conv_precision):
         assert ok, (name, info)
 
 
+FIRST_BLOCK_CASES = [
+    # B, H, W of the image, FromImage channels C, conv outputs N, pooled on load, biases
+    (2, 64, 64, 16, 16, False, True),
+    (3, 40, 24, 16, 32, True, True),         # ragged rows, pooled image
+    (2, 256, 256, 16, 16, True, True),       # the flagship critic's first layer pair
+    (1, 12, 20, 32, 32, False, False),
+    (5, 6, 6, 64, 16, False, True),          # image narrower than a workgroup's pixel span
+]
+
+
+@pytest.mark.parametrize("case", FIRST_BLOCK_CASES)
+def test_first_block_matches_unfused(ngan, case, conv_precision):
+    """ops.FirstBlock == ConvLReLUPN(FromImage(x)) for a one-colour image: forward, and the gradients of both layers' parameters
+    and of the image.  The fused form associates the sums differently (FromImage folded into the conv's weights first), so
+    pre-activations differ by rounding and single LeakyReLU ties may resolve differently: relative-L2 comparison."""
+    B, H, W, C, N, pool, use_bias = case
+    ops = ngan.ops
+    torch.manual_seed(sum(case[:5]))
+    x = torch.rand(B, H, W, 1, device=DEV) * 2 - 1
+    wf = torch.randn(C, 1, 1, 1, device=DEV).requires_grad_()
+    bf = (torch.randn(C, device=DEV) * 0.5).requires_grad_()
+    w = torch.randn(N, C, 3, 3, device=DEV).requires_grad_()
+    bc = (torch.randn(N, device=DEV) * 0.3).requires_grad_() if use_bias else None
+    scale = 1.3868 / np.sqrt(9 * C)
+    assert ops.first_block_fusable(x, wf, w)
+    params = [wf, bf, w] + ([bc] if use_bias else [])
+
+    def run(fused, linked=False):
+        xx = x.clone().requires_grad_()
+        link = ops.PNLink() if linked else None
+        if fused:
+            y, rn = ops.FirstBlock.apply(xx, wf, bf, w, bc, pool, scale, SLOPE, link)
+        else:
+            f = ops.FromImage.apply(xx, wf, bf, pool)
+            y, rn = ops.ConvLReLUPN.apply(f, w, bc, 0, scale, SLOPE, None, link) if linked else ops.ConvLReLUPN.apply(f, w, bc, 0, scale, SLOPE)
+        out = y
+        if linked:       # a consumer that applies this layer's LeakyReLU->PixelNorm backward in its input-gradient kernel
+            w2 = torch.ones(16, N, 3, 3, device=DEV) * 0.01 + torch.eye(16, N, device=DEV)[:, :, None, None]
+            out, _ = ops.ConvLReLUPN.apply(y, w2, None, 0, 0.2, SLOPE, link, ops.PNLink())
+        torch.manual_seed(1)
+        v = torch.randn_like(out)
+        g = torch.autograd.grad((out * v).sum(), [xx] + params)
+        return y.detach(), rn.detach(), [t.detach().clone() for t in g], (link.fused if linked else None)
+
+    y_ref, rn_ref, g_ref, _ = run(False)
+    y, rn, g, _ = run(True)
+    assert rel(y, y_ref) < 3e-5 and rel(rn, rn_ref) < 3e-5
+    names = ["x", "wf", "bf", "w"] + (["bc"] if use_bias else [])
+    for name, a, b in zip(names, g, g_ref):
+        ok, info = grad_close(a, b, 2e-4)
+        assert ok, (name, info)
+    _, _, g_ref, _ = run(False, linked=True)
+    _, _, g, was_fused = run(True, linked=True)
+    assert was_fused is True
+    for name, a, b in zip(names, g, g_ref):
+        ok, info = grad_close(a, b, 2e-4)
+        assert ok, ("linked", name, info)
+
+
+@pytest.mark.parametrize("case", [(2, 256, 256, 16, 16, True), (3, 40, 24, 16, 32, True), (2, 64, 64, 16, 16, False)])
+def test_first_block_matches_fp64_reference(ngan, case, conv_precision):
+    """ops.FirstBlock against plain torch in fp64 on the CPU (avg_pool2d -> conv 1x1 -> scaled conv 3x3 -> leaky_relu -> pixel
+    norm): forward and every gradient to 2e-6 relative L2, in both precision modes (the fused operator is exact fp32)."""
+    B, H, W, C, N, pool = case
+    ops = ngan.ops
+    torch.manual_seed(0)
+    x = torch.rand(B, H, W, 1, device=DEV) * 2 - 1
+    wf = torch.randn(C, 1, 1, 1, device=DEV).requires_grad_()
+    bf = (torch.randn(C, device=DEV) * 0.5).requires_grad_()
+    w = torch.randn(N, C, 3, 3, device=DEV).requires_grad_()
+    bc = (torch.randn(N, device=DEV) * 0.3).requires_grad_()
+    scale = 1.3868 / np.sqrt(9 * C)
+    xx = x.clone().requires_grad_()
+    y, _ = ops.FirstBlock.apply(xx, wf, bf, w, bc, pool, scale, SLOPE, None)
+    torch.manual_seed(1)
+    v = torch.randn(y.shape)
+    got = [y.detach()] + list(torch.autograd.grad((y * v.to(DEV)).sum(), [xx, wf, bf, w, bc]))
+
+    xr = x.double().cpu().permute(0, 3, 1, 2).clone().requires_grad_()
+    P = [t.detach().double().cpu().requires_grad_() for t in (wf, bf, w, bc)]
+    f = F.conv2d(F.avg_pool2d(xr, 2) if pool else xr, P[0], P[1])
+    a = F.leaky_relu(F.conv2d(f * scale, P[2], P[3], padding=1), SLOPE)
+    yr = (a / torch.sqrt((a * a).mean(1, keepdim=True) + 1e-8)).permute(0, 2, 3, 1)
+    g = torch.autograd.grad((yr * v.double()).sum(), [xr] + P)
+    want = [yr.detach(), g[0].permute(0, 2, 3, 1)] + list(g[1:])
+    for name, p_, q_ in zip(["y", "x", "wf", "bf", "w", "bc"], got, want):
+        err = float((p_.double().cpu() - q_).norm() / q_.norm())
+        assert err < 2e-6, (name, err)
+
+
+def test_first_block_accumulates_into_existing_grad(ngan):
+    """with a pre-existing contiguous .grad (the step driver's flat views) the conv weight's gradient is added in place"""
+    ops = ngan.ops
+    torch.manual_seed(5)
+    x = torch.rand(2, 32, 32, 1, device=DEV)
+    wf = torch.randn(16, 1, 1, 1, device=DEV).requires_grad_()
+    bf = torch.randn(16, device=DEV).requires_grad_()
+    w = torch.randn(16, 16, 3, 3, device=DEV).requires_grad_()
+    y, _ = ops.FirstBlock.apply(x, wf, bf, w, None, False, 0.1, SLOPE, None)
+    (gw,) = torch.autograd.grad(y.sum(), [w], retain_graph=True)
+    w.grad = torch.full_like(w, 2.0)
+    buf = w.grad.data_ptr()
+    y.sum().backward()
+    assert w.grad.data_ptr() == buf
+    assert rel(w.grad, gw + 2.0) < 1e-6
+
+
 @pytest.mark.parametrize("case", [(2, 128, 256, 16, 16, False), (2, 128, 256, 32, 16, True), (1, 200, 328, 16, 32, False)])
 def test_conv_to_image_fused(ngan, case, conv_precision):
     """ops.ConvLReLUPNToImage == ToImage(ConvLReLUPN(x)): forward with and without the stored activation, first-order gradients"""
