@@ -241,13 +241,13 @@ def main():
             # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3
             # passes over this same command; committed summary, see profiles/README.md).  null if no summary for this mode.
             traffic, traffic_src = None, None
-            tfile = os.path.join(ROOT, "profiles", f"r01_d_traffic_{args.precision}.json")
+            tfile = os.path.join(ROOT, "profiles", f"r01_e_traffic_{args.precision}.json")
             if os.path.exists(tfile) and args.res == 512 and args.batch == 16:
                 with open(tfile) as fh:
                     tk = json.load(fh)["kernels"].get(dom)
                 if tk:
                     traffic, traffic_src = tk["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
-            if "mid_kernel" in dom or ("persist" in dom and dom.rstrip(">").endswith(", 1")):   # split-bf16 instance: ~5x the fp32 MFMA rate, so HBM is the binding roof
+            if "mid_kernel" in dom or "up2f" in dom or ("persist" in dom and dom.rstrip(">").endswith(", 1")):   # split-bf16 instance: ~5x the fp32 MFMA rate, so HBM is the binding roof
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                    "algorithmic_bytes_per_launch": d["gbs"] * 1e9 * d["avg_us"] * 1e-6, "launches": d["launches"],

@@ -68,6 +68,59 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, __bf16* 
     packed[idx] = part == 0 ? hi : (__bf16)(v - (float)hi);
 }
 
+// Bilinear x2 folded into the weights ("precision 3", conv3x3_up2f_kernel below).  An output pixel (2i + py, 2j + px) of
+// conv3x3(up2(x)) only sees the 3x3 low-resolution neighbourhood of (i, j): hi-res row 2i + py + ky - 1 is a fixed blend of low-res
+// rows i-1, i, i+1, so  W_eff[py][px][dr][dc] = sum_{ky,kx} W[ky][kx] * E[py][ky][dr] * E[px][kx][dc]  with the blend table E
+// (align_corners = False taps .25/.75, ATen upsample_bilinear2d).  Four weight sets, one per output parity.
+__device__ __forceinline__ float up2_blend(int parity, int k, int d) {       // weight of low-res offset d-1 in hi-res offset k-1
+    // parity 0: rows 2i-1, 2i, 2i+1 -> (.75,.25,0) (.25,.75,0) (0,.75,.25);  parity 1: rows 2i, 2i+1, 2i+2 -> (.25,.75,0) (0,.75,.25) (0,.25,.75)
+    const int r = parity + k;                                               // 0..3: hi-res offset from row 2i-1
+    const float tab[4][3] = {{.75f, .25f, 0.f}, {.25f, .75f, 0.f}, {0.f, .75f, .25f}, {0.f, .25f, .75f}};
+    return tab[r][d];
+}
+
+__device__ __forceinline__ float up2_folded_weight(const float* __restrict__ w, int Cin, int n, int k, int set, int tap) {
+    const int py = set >> 1, px = set & 1, dr = tap / 3, dc = tap % 3;
+    const float* wk = w + ((long)n * Cin + k) * 9;
+    float v = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const float ey = up2_blend(py, ky, dr);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v = fmaf(wk[ky * 3 + kx], ey * up2_blend(px, kx, dc), v);
+    }
+    return v;
+}
+
+// element idx of a precision-3 packed weight: 4 sets in the split-bf16 layout, then the scaled fp32 OIHW weights (border pixels)
+__device__ __forceinline__ void pack_up2f_element(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, float scale,
+                                                  long idx) {
+    const int K = Cin, N = Cout, MT = N / 16, nstep = K == 16 ? 5 : 9 * (K / 32);
+    const long E = (long)nstep * MT * 2 * 64 * 8;
+    if (idx >= 4 * E) {
+        const long r = idx - 4 * E;
+        dst[2 * E + r] = w[r] * scale;
+        return;
+    }
+    const int set = (int)(idx / E);
+    const long li = idx - set * E;
+    const int j = li & 7, lane = (li >> 3) & 63, part = (li >> 9) & 1;
+    const long r = li >> 10;
+    const int mt = r % MT, step = r / MT;
+    const int n = mt * 16 + (lane & 15), kk = 8 * (lane >> 4) + j;
+    const int tap = K == 16 ? 2 * step + (kk >> 4) : step % 9;
+    const int k = K == 16 ? (kk & 15) : (step / 9) * 32 + kk;
+    float v = tap < 9 ? up2_folded_weight(w, Cin, n, k, set, tap) * scale : 0.f;
+    const __bf16 hi = (__bf16)v;
+    reinterpret_cast<__bf16*>(dst)[idx] = part == 0 ? hi : (__bf16)(v - (float)hi);
+}
+
+__global__ void pack_weights_up2f_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, float scale,
+                                         long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) pack_up2f_element(w, packed, Cout, Cin, scale, idx);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward / dgrad kernel.  256 threads = 4 waves arranged WP (along pixels) x WN (along output channels).
 // A wave owns PGW pixel groups (16 consecutive pixels of one tile row each) x MTW 16-channel tiles; the block
@@ -251,6 +304,18 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 // tile t+1 before the MFMAs of tile t, so every CU always has a tile's worth of loads in flight.
 // Bilinear x2 input: the low-resolution source patch (6x18 pixels) is staged once and expanded LDS -> LDS.
 // ---------------------------------------------------------------------------------------------------------
+// "The value must be in its registers HERE": an empty asm that reads and writes v (conv3x3_up2f_kernel).  (a) On the prefetched tile
+// registers right after the MFMAs, before the epilogue's stores are issued: gfx9 counts loads and stores in ONE counter (vmcnt) and
+// they may retire out of order with each other, so once stores are in flight the compiler can only wait for a load with vmcnt(0),
+// i.e. by draining every store of the tile just written.  (b) On loop-invariant operands the compiler would otherwise re-load
+// inside the loop.  (Measured on the older persistent kernel the same treatment was neutral to slightly negative -- its tile loop
+// is bound by VALU issue and LDS, not by the store drain -- so it keeps the compiler's placement.)
+__device__ __forceinline__ void pin_registers(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// ... and not before `dep` has been computed (an accumulator of the last MFMA: the scheduler may not hoist the wait above the MFMAs)
+__device__ __forceinline__ void pin_registers_after(float4& v, float& dep) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dep));
+}
+
 // float index of the hi half of (16-channel group g, channel quad c4) of tile pixel (ty, tx) in the split-bf16 image
 template <int KG, int PLANE, int LP>
 __device__ __forceinline__ int bf16_slot(int g, int c4, int ty, int tx) {
@@ -278,13 +343,14 @@ __device__ __forceinline__ void st_split(float* tile, int idx, float4 v) {
 // PREC = 1: split-bf16 arithmetic (3 x v_mfma_f32_16x16x32_bf16 per fp32 product group, fp32 accumulate): the fp32 input
 // is split into hi/lo bf16 halves while the tile is staged; LDS image per pixel (K = 16): [hi c0-7][hi c8-15][lo c0-7]
 // [lo c8-15] (16 B each, same 64 B and the same rotation as the fp32 image); K = 32: plane 0 = hi, plane 1 = lo.
-constexpr int persist_tile_h(int MTW, int KG) { return MTW * KG == 4 ? 4 : 8; }
+// (the bilinear 32-channel instances also use 4 rows: with 8 their tile + low-res patch + weights come to 83 KB, one workgroup per CU)
+constexpr int persist_tile_h(int MTW, int KG, int RES) { return (MTW * KG == 4 || (KG == 2 && RES == NGAN_RESAMPLE_UP2)) ? 4 : 8; }
 
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
     // tile: 8 x 32 pixels, 4 pixel groups of 16 per wave; the 32 -> 32 instances use 4 x 32 (2 groups per wave): their 8-row tile
     // needs 88 KB of LDS and ~260 registers, i.e. ONE workgroup per CU with nothing to overlap its load / barrier / MFMA phases
-    constexpr int THc = persist_tile_h(MTW, KG), PGW = THc / 2, RPW = THc / 4;
+    constexpr int THc = persist_tile_h(MTW, KG, RES), PGW = THc / 2, RPW = THc / 4;
     constexpr int TWc = 32, HH_ = THc + 2, HW_ = TWc + 2, NPIX = HH_ * HW_, LP = 40;
     constexpr int PH = THc / 2 + 2, PW = TWc / 2 + 2, NPP = PH * PW;
     constexpr int NSTEP = KG == 1 ? 5 : 9;   // bf16x3: K = 32 contraction steps per tile
@@ -530,6 +596,22 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE)
                 rn_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rn + img, 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
         }
+        // PixelNorm-backward operands that were not prefetched: all of the tile's loads before its first store (a load issued behind a
+        // store can only be awaited by draining that store, see pin_registers)
+        constexpr bool LATE = EPI == EPI_PN_BWD && OUTMODE == 0 && !PRE;
+        float4 yy_epi[LATE ? PGW : 1][MTW];
+        float rn_epi[LATE ? PGW : 1];
+        if (LATE) {
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) {
+                const int gy = y0 + wave * RPW + (pg >> 1), gx = x0 + (pg & 1) * 16 + p;
+                const bool valid = gy < a.H && gx < a.W;
+                const long pix = img + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) yy_epi[pg][mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
+                rn_epi[pg] = a.arn[pix];
+            }
+        }
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg) {
             const int row = wave * RPW + (pg >> 1), col = (pg & 1) * 16 + p;
@@ -570,16 +652,9 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 // backward of the LeakyReLU -> PixelNorm that produced this layer's input, applied to the gradient just computed
                 float4 yy[MTW];
                 float rr;
-                if (PRE) {
 #pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) yy[mt] = yy_pre[PRE ? pg : 0][mt];
-                    rr = rn_pre[PRE ? pg : 0];
-                } else {
-                    const long pix = img + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) yy[mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
-                    rr = a.arn[pix];
-                }
+                for (int mt = 0; mt < MTW; ++mt) yy[mt] = PRE ? yy_pre[PRE ? pg : 0][mt] : yy_epi[PRE ? 0 : pg][mt];
+                rr = PRE ? rn_pre[PRE ? pg : 0] : rn_epi[PRE ? 0 : pg];
                 float s = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) s += f4dot(v[mt], yy[mt]);
@@ -640,10 +715,257 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// conv3x3(bilinear_x2(x)) with the up-sampling folded into four parity weight sets (split-bf16, N = 16 outputs, K = 16 / 32).
+// The tile is 8 x 32 OUTPUT pixels = 4 x 16 low-resolution pixels; only their 6 x 18 halo patch is staged (split into bf16 hi/lo
+// once per low-res value) -- there is no expansion to the output resolution at all.  Wave w owns parity (py, px) = (w >> 1, w & 1):
+// its weight set lives in registers, its 4 pixel groups are the 4 low-res rows, and its B operands are read from the same patch
+// cells as the other waves'.  (Measured alternatives for K = 16: 4 workgroups per CU 180-195 us instead of 167; one low-res row per
+// wave with all four weight sets in registers -- 4x fewer LDS reads, 2 workgroups per CU -- 190-197 us.)  Output pixels on the image border (whose 3x3 window reaches into the conv's zero padding, which
+// the folded weights cannot express) are skipped here and written by conv3x3_up2_border_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int KG, int EPI>
+__global__ __launch_bounds__(256, KG == 1 ? 3 : 2) void conv3x3_up2f_kernel(ConvArgs a, int n_tiles) {
+    constexpr int K = KG * 16, N = 16, LP = 24, PH = 6, PW = 18, NPP = PH * PW;
+    constexpr int NSTEP = KG == 1 ? 5 : 9;
+    constexpr int PLANE = PH * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int N_SRC = KG * NPP * 4, NST = (N_SRC + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float tile[TILE_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int py = wave >> 1, px = wave & 1;
+    const int h = a.H >> 1, w = a.W >> 1;
+
+    bf16x8 wh[NSTEP], wlo[NSTEP];
+    {
+        const float* wset = a.wp + (long)wave * (NSTEP * 2 * 256);
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            float4 h4 = ld4(wset + (st * 2 + 0) * 256 + lane * 4), l4 = ld4(wset + (st * 2 + 1) * 256 + lane * 4);
+            pin_registers(h4);                 // loaded once: not to be re-loaded per tile
+            pin_registers(l4);
+            wh[st] = __builtin_bit_cast(bf16x8, h4);
+            wlo[st] = __builtin_bit_cast(bf16x8, l4);
+        }
+    }
+    const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+    const int band = (n_tiles + 7) >> 3;
+    const int t_end = min((xcd + 1) * band, n_tiles);
+    int t = xcd * band + (blockIdx.x >> 3);
+
+    int s_ty[NST], s_tx[NST], s_ch[NST], s_lds[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = tid + i * 256;
+        const int c4 = e & 3, pp = (e >> 2) % NPP, g = (e >> 2) / NPP;
+        s_ty[i] = pp / PW - 1; s_tx[i] = pp % PW - 1; s_ch[i] = (g * 16 + c4 * 4) * 4;
+        s_lds[i] = bf16_slot<KG, PLANE, LP>(g, c4, pp / PW, pp % PW);
+    }
+    int rs[NSTEP];
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        int tap = KG == 1 ? 2 * st + (q >> 1) : st;
+        if (tap > 8) tap = 8;                                  // zero-weight padding tap: any valid address
+        const int dy = tap / 3, dx = tap % 3;
+        const int slot = (KG == 1 ? (q & 1) : q) ^ ((((p + dx) >> 2) & 1) << 1);
+        rs[st] = (dy * LP + p + dx) * 16 + slot * 4;
+    }
+    auto decode = [&](int tt, int& b, int& y0, int& x0) {
+        const int txi = tt % a.tiles_x; tt /= a.tiles_x;
+        const int tyi = tt % a.tiles_y;
+        b = tt / a.tiles_y;
+        y0 = tyi * 8; x0 = txi * 32;
+    };
+    float4 stg[NST];
+    const unsigned src_img_bytes = (unsigned)(h * w * K) * 4u;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    auto issue = [&](int tt) {                 // always called unconditionally (see the persistent kernel)
+        int b, y0, x0;
+        decode(tt, b, y0, x0);
+        const float* base = a.x + (long)b * h * w * K;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, src_img_bytes, 0x00020000);
+        const int ly0 = y0 >> 1, lx0 = x0 >> 1;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int ly = min(max(ly0 + s_ty[i], 0), h - 1), lx = min(max(lx0 + s_tx[i], 0), w - 1);   // the bilinear taps clamp
+            const unsigned off = (tid + i * 256 < N_SRC) ? (unsigned)((ly * w + lx) * K * 4 + s_ch[i]) : OOB;
+            stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        }
+    };
+    if (t >= t_end) return;                                // (uniform over the workgroup)
+    issue(t);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) pin_registers(stg[i]);   // (no load is pending on entry to the loop: see pin_registers)
+    const float4 bv = a.bias ? ld4(a.bias + q * 4) : f4zero();
+    const float inv_n = 1.0f / (float)N;
+
+    while (t < t_end) {
+        int b, y0, x0;
+        decode(t, b, y0, x0);
+        __syncthreads();   // the previous tile's MFMAs have finished reading `tile`
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (tid + i * 256 < N_SRC) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
+        __syncthreads();
+        const int tn = t + nper;
+        issue(min(tn, t_end - 1));   // in flight while this tile is computed
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would otherwise sink the loads to their first use, behind the MFMAs)
+        f32x4 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            bf16x8 xh[4], xl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int base = r * LP * 16 + rs[st];
+                xh[r] = *reinterpret_cast<const bf16x8*>(&tile[base]);
+                xl[r] = *reinterpret_cast<const bf16x8*>(&tile[KG == 1 ? (base ^ 8) : (base + PLANE)]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[st], xh[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st], xl[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st], xh[r], acc[r], 0, 0, 0);
+        }
+        {
+            float dep = acc[3][3];
+#pragma unroll
+            for (int i = 0; i < NST; ++i) pin_registers_after(stg[i], dep);   // next tile's loads land before this tile's stores go out
+            acc[3][3] = dep;
+        }
+        const long img = (long)b * a.H * a.W;
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img * N, 0, (unsigned)(a.H * a.W * N) * 4u, 0x00020000);
+        __amdgpu_buffer_rsrc_t rn_rsrc;
+        if (EPI == EPI_LRELU_PN) rn_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rn + img, 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = y0 + 2 * r + py, gx = x0 + 2 * p + px;
+            // interior pixels only: the border ring belongs to conv3x3_up2_border_kernel
+            const bool valid = gy > 0 && gy < a.H - 1 && gx > 0 && gx < a.W - 1;
+            float4 c = make_float4(acc[r][0] + bv.x, acc[r][1] + bv.y, acc[r][2] + bv.z, acc[r][3] + bv.w);
+            if (EPI == EPI_LRELU_PN) {
+                c.x = fmaxf(c.x, a.slope * c.x); c.y = fmaxf(c.y, a.slope * c.y);
+                c.z = fmaxf(c.z, a.slope * c.z); c.w = fmaxf(c.w, a.slope * c.w);
+                float ss = f4dot(c, c);
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                const float m = ss * inv_n + a.eps;
+                const float inv = __builtin_amdgcn_rsqf(m);
+                c = f4scale(c, inv);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m * inv), rn_rsrc, (valid && q == 0) ? (unsigned)((gy * a.W + gx) * 4) : OOB, 0, 0);
+            }
+            const unsigned off = valid ? (unsigned)(((gy * a.W + gx) * N + q * 4) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, c), y_rsrc, off, 0, 0);
+        }
+        t = tn;
+    }
+}
+
+// The border ring of conv3x3(bilinear_x2(x)) (rows 0, H-1, columns 0, W-1) in exact fp32 from the unfolded weights: 16 pixels per
+// workgroup, thread = (pixel, output channel); the 3x3 up-sampled window of each pixel is staged in LDS (zeros outside the image).
+template <int EPI, int K>
+__global__ __launch_bounds__(256) void conv3x3_up2_border_kernel(ConvArgs a, const float* __restrict__ wraw) {
+    constexpr int N = 16, KQ = K / 4;
+    constexpr int NW = N * K * 9 / 256;                 // weight elements per thread (9 or 18, exact)
+    constexpr int NU = (16 * 9 * KQ + 255) / 256;       // window quads per thread (3 or 5)
+    __shared__ __attribute__((aligned(16))) float u[16 * 9 * K];   // [16 px][9 taps][K]
+    __shared__ float wt[9 * K * 16];                                // [tap][k][n]
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int nborder = 2 * a.W + 2 * (a.H - 2);
+    auto pixel = [&](int idx, int& gy, int& gx) {
+        if (idx < a.W) { gy = 0; gx = idx; }
+        else if (idx < 2 * a.W) { gy = a.H - 1; gx = idx - a.W; }
+        else { const int j = idx - 2 * a.W; gy = 1 + (j >> 1); gx = (j & 1) ? a.W - 1 : 0; }
+    };
+    // every global load of the workgroup is issued before the first LDS store: one memory round trip, not one per loop iteration
+    float wv[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) wv[i] = wraw[tid + i * 256];
+    float4 uv[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int e = tid + i * 256;
+        const int cq = e % KQ, tap = (e / KQ) % 9, pxi = e / (9 * KQ);
+        const int idx = blockIdx.x * 16 + pxi;
+        uv[i] = f4zero();
+        if (e < 16 * 9 * KQ && idx < nborder) {
+            int gy, gx;
+            pixel(idx, gy, gx);
+            uv[i] = load_resampled<NGAN_RESAMPLE_UP2>(a.x, b, gy + tap / 3 - 1, gx + tap % 3 - 1, cq * 4, a.H, a.W, K);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int e = tid + i * 256;
+        const int tap = e % 9, k = (e / 9) % K, n = e / (9 * K);
+        wt[(tap * K + k) * 16 + n] = wv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int e = tid + i * 256;
+        if (e < 16 * 9 * KQ) st4(&u[e * 4], uv[i]);     // e = (pxi*9 + tap)*KQ + cq  ->  u[(pxi*9 + tap)*K + 4*cq]
+    }
+    __syncthreads();
+    const int pxi = tid >> 4, n = tid & 15;
+    const int idx = blockIdx.x * 16 + pxi;
+    // four independent partial sums, four contraction indices per LDS read of the window
+    float c0 = a.bias ? a.bias[n] : 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    const float4* u4 = reinterpret_cast<const float4*>(u + pxi * 9 * K);
+#pragma unroll 6
+    for (int t4 = 0; t4 < 9 * K / 4; ++t4) {
+        const float4 x4 = u4[t4];
+        const float* wp = wt + t4 * 64 + n;
+        c0 = fmaf(x4.x, wp[0], c0); c1 = fmaf(x4.y, wp[16], c1);
+        c2 = fmaf(x4.z, wp[32], c2); c3 = fmaf(x4.w, wp[48], c3);
+    }
+    float c = (c0 + c1) + (c2 + c3);
+    float r = 1.f;
+    if (EPI == EPI_LRELU_PN) {
+        c = fmaxf(c, a.slope * c);
+        const float ss = group_sum<16>(c * c);
+        r = sqrtf(ss / (float)N + a.eps);
+        c /= r;
+    }
+    if (idx < nborder) {
+        int gy, gx;
+        pixel(idx, gy, gx);
+        const long pix = ((long)b * a.H + gy) * a.W + gx;
+        a.y[pix * N + n] = c;
+        if (EPI == EPI_LRELU_PN && n == 0) a.rn[pix] = r;
+    }
+}
+
+template <int KG, int EPI>
+int launch_up2f(ConvArgs a, hipStream_t s) {
+    a.tiles_x = ngan::ceil_div(a.W, 32);
+    a.tiles_y = ngan::ceil_div(a.H, 8);
+    const int n_tiles = a.B * a.tiles_x * a.tiles_y;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_up2f_kernel<KG, EPI>, 256, 0) != hipSuccess || n < 1) n = 1;
+        per_cu = n > 4 ? 4 : n;
+    }
+    int grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    grid &= ~7;
+    if (grid < 8) grid = 8;
+    constexpr int NSTEP = KG == 1 ? 5 : 9;
+    const float* wraw = a.wp + 4 * (NSTEP * 2 * 256);           // the scaled OIHW weights behind the four folded sets
+    hipLaunchKernelGGL((conv3x3_up2f_kernel<KG, EPI>), dim3(grid), dim3(256), 0, s, a, n_tiles);
+    int st = ngan::launch_status("ngan_conv3x3_fwd(bilinear folded)");
+    if (st) return st;
+    const int nborder = 2 * a.W + 2 * (a.H - 2);
+    hipLaunchKernelGGL((conv3x3_up2_border_kernel<EPI, KG * 16>), dim3(ngan::ceil_div(nborder, 16), a.B), dim3(256), 0, s, a, wraw);
+    return ngan::launch_status("ngan_conv3x3_fwd(bilinear border)");
+}
+
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 int launch_persist(ConvArgs a, hipStream_t s) {
     a.tiles_x = ngan::ceil_div(a.W, 32);
-    a.tiles_y = ngan::ceil_div(a.H, persist_tile_h(MTW, KG));
+    a.tiles_y = ngan::ceil_div(a.H, persist_tile_h(MTW, KG, RES));
     const int n_tiles = a.B * a.tiles_x * a.tiles_y;
     // persistent grid = what is actually resident (registers and LDS both limit it): an over-subscribed static
     // tile partition would serialise whole workgroups behind each other
@@ -707,6 +1029,13 @@ int pick_cfg(int mti, int B, int H, int W) {
 // the persistent kernel (and with it the split-bf16 arithmetic) applies to few-channel layers on large images
 inline bool persist_eligible(int B, int H, int W, int K, int N, int resample) {
     return N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && pick_cfg(N / 16 - 1, B, H, W) == 0;
+}
+
+// bilinear x2 folded into the weights (precision code 3): the persistent kernel's shapes with 16 outputs, and an interior to speak of
+inline bool up2f_eligible(int B, int H, int W, int K, int N, int resample) {
+    static const bool enabled = !(getenv("NGAN_UP2_FOLDED") && getenv("NGAN_UP2_FOLDED")[0] == '0');   // A/B switch for measurements
+    return enabled && resample == NGAN_RESAMPLE_UP2 && N == 16 && (K == 16 || K == 32) && H % 2 == 0 && W % 2 == 0 && H >= 16 && W >= 32 &&
+           persist_eligible(B, H, W, K, N, resample);
 }
 
 template <int MTI, int CI, int RES, int EPI, int OUTMODE>
@@ -1121,7 +1450,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
     p.tiles_x = ngan::ceil_div(W, p.tw);
     p.tiles_y = ngan::ceil_div(H, 256 / p.tw);
     p.n_tiles = B * p.tiles_x * p.tiles_y;
-    int cap = 512 / p.nslices;   // about two resident workgroups per CU: few slabs to reduce afterwards
+    int cap = 512 / p.nslices;   // about two resident workgroups per CU: few slabs to reduce afterwards (256 / 768 measured slower)
     if (cap < 1) cap = 1;
     p.nwx = p.n_tiles < cap ? p.n_tiles : cap;
     return p;
@@ -1173,6 +1502,7 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackEntry* __restr
     const PackEntry e = table[lo];
     const long idx = gidx - e.first;
     const int Cout = e.cout, Cin = e.cin, mode = e.mode;
+    if (e.precision == 3) { pack_up2f_element(e.src, e.dst, Cout, Cin, e.scale, idx); return; }
     const int Kreal = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
     const int K = e.precision == 2 ? 32 : Kreal;
     if (e.precision == 0) {
@@ -1213,6 +1543,7 @@ extern "C" long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int prec
     if (precision == 0) return 9L * Cin * Cout;
     const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
     if (precision == 2) return K == 16 ? bf16x3_elements(32, N) : 0;      // K = 16 padded to 32 (mid kernel)
+    if (precision == 3) return mode == 0 && bf16x3_elements(K, N) ? 4 * bf16x3_elements(K, N) + 9L * K * N : 0;   // folded bilinear
     return bf16x3_elements(K, N);
 }
 
@@ -1230,12 +1561,14 @@ extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
         const long p0 = Cin == 16 ? bf16x3_elements(32, Cout) : 0, p1 = Cout == 16 ? bf16x3_elements(32, Cin) : 0;
         return ((p0 > p1 ? p0 : p1) + 1) / 2;
     }
+    if (precision == 3) return bf16x3_elements(Cin, Cout) ? 2 * bf16x3_elements(Cin, Cout) + 9L * Cin * Cout : 0;
     const long e0 = bf16x3_elements(Cin, Cout), e1 = bf16x3_elements(Cout, Cin);   // forward / flipped orientation
     return ((e0 > e1 ? e0 : e1) + 1) / 2;
 }
 
 extern "C" int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision) {
     if (precision != 1 || B <= 0 || H <= 0 || W <= 0) return 0;
+    if (up2f_eligible(B, H, W, K, N, resample)) return 3;
     if (persist_eligible(B, H, W, K, N, resample)) return 1;
     if (ngan::conv3x3_mid_eligible(B, H, W, K, N)) return 1;
     // K = 16 into 32..128 channels where the persistent kernel does not apply (pooled input, small images): the mid kernel with the
@@ -1249,7 +1582,14 @@ extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int
     NGAN_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_pack_weights: Cin=%d, Cout=%d must be positive multiples of 16", Cin, Cout);
     NGAN_REQUIRE(mode == 0 || mode == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: mode %d", mode);
-    NGAN_REQUIRE(precision >= 0 && precision <= 2, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
+    NGAN_REQUIRE(precision >= 0 && precision <= 3, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
+    if (precision == 3) {
+        const long tot = ngan_conv3x3_pack_elements(Cout, Cin, mode, 3);
+        NGAN_REQUIRE(tot > 0, NGAN_ERR_SHAPE, "conv3x3_pack_weights: precision 3 (folded bilinear) needs mode 0 and K = 16 or a multiple of 32");
+        hipLaunchKernelGGL(pack_weights_up2f_kernel, dim3(ngan::ceil_div(tot, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, packed,
+                           Cout, Cin, scale, tot);
+        return ngan::launch_status("ngan_conv3x3_pack_weights(folded bilinear)");
+    }
     if (precision >= 1) {
         const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
         NGAN_REQUIRE(precision == 1 || K == 16, NGAN_ERR_SHAPE, "conv3x3_pack_weights: precision 2 is the K = 16 padded layout (K=%d)", K);
@@ -1302,6 +1642,12 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
     if (persist_eligible(B, H, W, K, N, resample)) {
         // large image, few channels: persistent pipelined kernel (32-bit byte offsets inside one image)
         NGAN_REQUIRE((long)H * W * (K > N ? K : N) * 16 < (1L << 32), NGAN_ERR_SHAPE, "conv3x3_fwd: one image must stay below 1 GiB (H=%d W=%d)", H, W);
+        if (precision == 3) {
+            NGAN_REQUIRE((epilogue == EPI_NONE || epilogue == EPI_LRELU_PN) && out_mode == 0, NGAN_ERR_ARG,
+                         "conv3x3_fwd: the folded bilinear kernel has epilogues 0 and 1");
+            if (K == 16) return epilogue ? launch_up2f<1, EPI_LRELU_PN>(a, s) : launch_up2f<1, EPI_NONE>(a, s);
+            return epilogue ? launch_up2f<2, EPI_LRELU_PN>(a, s) : launch_up2f<2, EPI_NONE>(a, s);
+        }
         if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, precision, s)
                                     : dispatch_persist<1, 2>(a, resample, epilogue, out_mode, precision, s);
         return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, precision, s)
@@ -1336,7 +1682,9 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     NGAN_REQUIRE(N == 16 || N == 32 || N == 64 || N == 128, NGAN_ERR_SHAPE, "conv3x3_kernel_name: N=%d", N);
     const int mti = N == 16 ? 0 : N == 32 ? 1 : N == 64 ? 2 : 3;
     const int ci = pick_cfg(mti, B, H, W);
-    if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0)
+    if (precision == 3)
+        snprintf(buf, len, "conv3x3_up2f_kernel<%d, %d>", K / 16, epilogue);
+    else if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0)
         snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
                  (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision);
     else if (precision >= 1 && ngan::conv3x3_mid_eligible(B, H, W, precision == 2 ? 32 : K, N))
@@ -1364,6 +1712,9 @@ struct ReduceEntry {
 constexpr int kReduceBatch = 24;
 struct ReduceBatch { ReduceEntry e[kReduceBatch]; int n; };
 
+// One workgroup sums kReduceSpan consecutive elements of a gradient over all slabs: a wave reads 256 contiguous bytes of one slab
+// per load (whole cache lines; 16-element spans fetched half-used 128-byte lines), the 4 waves take every 4th slab each.
+constexpr int kReduceSpan = 64;
 __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(ReduceBatch b) {
     __shared__ float red[256];
     int ei = 0;
@@ -1372,35 +1723,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(ReduceBatch b) {
     const ReduceEntry& e = b.e[ei];
     const int slab = 9 * e.co_s * e.ci_s;
     const long M = (long)e.nslices * slab;
-    const int tid = threadIdx.x;
-    const long i = (long)(blockIdx.x - e.first_block) * 16 + (tid & 15);
+    const int tid = threadIdx.x, el = tid & (kReduceSpan - 1), grp = tid / kReduceSpan;
+    constexpr int NG = 256 / kReduceSpan;
+    const long i = (long)(blockIdx.x - e.first_block) * kReduceSpan + el;
     float total = 0.f;
     for (int s = 0; s < e.nsrc; ++s) {
         float acc = 0.f;
         if (i < M) {
-            // four independent partial sums: the slab reads of one thread are all in flight instead of one per round trip
+            // eight independent partial sums: the slab reads of one thread are in flight together instead of one per round trip
             const float* src = e.partial[s] + i;
             const int np = e.nparts[s];
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int j = tid >> 4;
-            for (; j + 48 < np; j += 64) {
-                a0 += src[(long)j * M]; a1 += src[(long)(j + 16) * M];
-                a2 += src[(long)(j + 32) * M]; a3 += src[(long)(j + 48) * M];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+            int j = grp;
+            for (; j + 7 * NG < np; j += 8 * NG) {
+                a0 += src[(long)j * M]; a1 += src[(long)(j + NG) * M];
+                a2 += src[(long)(j + 2 * NG) * M]; a3 += src[(long)(j + 3 * NG) * M];
+                a4 += src[(long)(j + 4 * NG) * M]; a5 += src[(long)(j + 5 * NG) * M];
+                a6 += src[(long)(j + 6 * NG) * M]; a7 += src[(long)(j + 7 * NG) * M];
             }
-            for (; j < np; j += 16) a0 += src[(long)j * M];
+            for (; j < np; j += NG) a0 += src[(long)j * M];
+            a0 += a4; a1 += a5; a2 += a6; a3 += a7;
             acc = (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
         red[tid] = acc;
         __syncthreads();
-        if (tid < 16) {
+        if (tid < kReduceSpan) {
             float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) t += red[tid + 16 * j];
+            for (int j = 0; j < NG; ++j) t += red[tid + kReduceSpan * j];
             total = fmaf(t, e.scale[s], total);
         }
     }
-    if (tid < 16 && i < M) {
+    if (tid < kReduceSpan && i < M) {
         int r = (int)(i % slab);
         const int slice = (int)(i / slab);
         const int ci_l = r % e.ci_s; r /= e.ci_s;
@@ -1439,7 +1794,7 @@ extern "C" int ngan_conv3x3_wgrad_reduce_many(const void* entries, int n, void* 
             b.e[i] = src[base + i];
             NGAN_REQUIRE(b.e[i].nsrc >= 1 && b.e[i].nsrc <= 4 && b.e[i].gw, NGAN_ERR_ARG, "conv3x3_wgrad_reduce_many: bad entry %d", base + i);
             b.e[i].first_block = blocks;
-            blocks += ngan::ceil_div((long)b.e[i].nslices * 9 * b.e[i].co_s * b.e[i].ci_s, 16);
+            blocks += ngan::ceil_div((long)b.e[i].nslices * 9 * b.e[i].co_s * b.e[i].ci_s, kReduceSpan);
         }
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
         int st = ngan::launch_status("ngan_conv3x3_wgrad_reduce_many");

@@ -174,16 +174,23 @@ __global__ __launch_bounds__(256) void first_block_finish_kernel(const float* __
         const float v = scale * (wf[c] * S1[t * N + n] + (bf ? bf[c] : 0.f) * S0[t * N + n]);
         gW[e] = accumulate ? gW[e] + v : v;
     }
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    // FromImage gradients: 16 lanes share one channel c (each takes every 16th of the N*9 products), 16 channels per pass
+    for (int c0 = 0; c0 < C; c0 += 16) {
+        const int c = c0 + (threadIdx.x >> 4), part = threadIdx.x & 15;
         float a = 0.f, b = 0.f;
-        for (int n = 0; n < N; ++n)
-            for (int t = 0; t < 9; ++t) {
+        if (c < C)
+            for (int e = part; e < N * 9; e += 16) {
+                const int n = e / 9, t = e - n * 9;
                 const float w = W[((long)n * C + c) * 9 + t];
                 a = fmaf(w, S1[t * N + n], a);
                 b = fmaf(w, S0[t * N + n], b);
             }
-        gwf[c] = a * scale;
-        if (gbf) gbf[c] = b * scale;
+        a = group_sum<16>(a);
+        b = group_sum<16>(b);
+        if (c < C && part == 0) {
+            gwf[c] = a * scale;
+            if (gbf) gbf[c] = b * scale;
+        }
     }
     if (gbc)                                                    // conv bias: sum over pixels of gc = S0 at the centre tap
         for (int n = threadIdx.x; n < N; n += blockDim.x) gbc[n] = S0[4 * N + n];

@@ -113,6 +113,7 @@ CONV_CASES = [
     (2, 128, 256, 16, 16, 0, True), (2, 128, 256, 32, 16, 0, False), (2, 128, 256, 16, 32, 0, False), (2, 128, 256, 32, 32, 0, True),
     (2, 128, 256, 16, 16, 2, False), (2, 128, 256, 32, 16, 2, False), (2, 128, 256, 32, 32, 2, False),
     (1, 200, 328, 16, 16, 0, False),   # ragged right / bottom edges on the persistent path
+    (2, 136, 296, 16, 16, 2, True), (2, 136, 296, 32, 16, 2, True),   # bilinear input folded into the weights: ragged edges, bias
     # split-bf16 kernel for many channels on small images (csrc/conv3x3_mid.hip; exact-fp32 mode runs the generic kernel):
     # all output channels in one workgroup (fused PixelNorm) for N = 32 / 64 / 128 ...
     (4, 64, 64, 64, 32, 0, False), (4, 64, 64, 32, 64, 0, True), (4, 64, 64, 32, 128, 0, True),
