@@ -49,14 +49,20 @@ int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int 
 /* precision 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32).  precision 1: "bf16x3" -- every fp32 operand is split into
  * hi = bf16(v), lo = bf16(v - hi) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation (relative error ~1e-5 per product instead of ~1e-7; ~5x the fp32 MFMA rate, which makes these layers
- * HBM-bound).  It exists for few-channel layers on large images (K, N in {16, 32}); ask before packing / calling: */
+ * HBM-bound).  Ask before packing / calling -- the answer is the precision CODE to pack with and to pass to the conv call:
+ *   0 exact fp32;  1 split-bf16;  2 split-bf16 with a K = 16 contraction zero-padded to 32 (its own packed layout);
+ *   3 split-bf16 with the bilinear x2 of `resample` 2 folded into the weights (N = 16, K in {16, 32}, large images): `packed` then
+ *     holds four 3x3 weight sets over the LOW-resolution input, one per output parity (py, px),
+ *     W_eff[dr][dc] = sum_{ky,kx} W[ky][kx] * E[py][ky][dr] * E[px][kx][dc]  (E: the .25/.75 blend rows of upsample_bilinear2d,
+ *     align_corners = False), followed by the scaled fp32 weights for the one-pixel border ring (mode 0 only). */
 int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision);
 long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision);   /* size of `packed` in floats */
 
 /* Re-pack many weights with ONE launch (after an optimiser step).  `table` is a device array of n_entries records
  *   { const float* src; float* dst; int Cout, Cin, mode, precision; float scale; int pad; long first; }          (48 bytes)
  * where `first` is the running sum of ngan_conv3x3_pack_elements(...) over the preceding entries (the unit is one packed
- * element: a float for precision 0, a bf16 for precision 1) and total_elements is the sum over all entries. */
+ * element: a float for precision 0, a bf16 for precision 1 / 2, precision 3: bf16 for the four sets, then one per raw fp32
+ * weight) and total_elements is the sum over all entries. */
 long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int precision);
 int ngan_conv3x3_pack_many(const void* table, int n_entries, long total_elements, void* stream);
 
