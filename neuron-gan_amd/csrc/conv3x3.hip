@@ -676,6 +676,19 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             } else {
                 const long W2 = 2L * a.W;
                 const long o00 = 4 * img + (long)(2 * (valid ? gy : 0)) * W2 + 2 * (valid ? gx : 0);
+                // the four pooled-over pixels' PixelNorm-backward operands: all loads before the first of the four stores (a load
+                // issued behind a store is awaited by draining that store, see pin_registers)
+                float4 yy4[EPI == EPI_PN_BWD ? 4 : 1][MTW];
+                float rr4[EPI == EPI_PN_BWD ? 4 : 1];
+                if (EPI == EPI_PN_BWD) {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        const long pix = o00 + (sub >> 1) * W2 + (sub & 1);
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) yy4[sub][mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
+                        rr4[sub] = a.arn[pix];
+                    }
+                }
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
                     const long pix = o00 + (sub >> 1) * W2 + (sub & 1);
@@ -687,13 +700,13 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                         float s = 0.f;
 #pragma unroll
                         for (int mt = 0; mt < MTW; ++mt) {
-                            yy[mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
+                            yy[mt] = yy4[EPI == EPI_PN_BWD ? sub : 0][mt];
                             s += f4dot(o4[mt], yy[mt]);
                         }
                         s += __shfl_xor(s, 16, 64);
                         s += __shfl_xor(s, 32, 64);
                         s *= inv_n;
-                        const float inv_r = 1.0f / a.arn[pix];
+                        const float inv_r = 1.0f / rr4[EPI == EPI_PN_BWD ? sub : 0];
 #pragma unroll
                         for (int mt = 0; mt < MTW; ++mt) o4[mt] = pn_bwd4(o4[mt], yy[mt], s, inv_r, a.slope);
                     }
