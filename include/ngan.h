@@ -85,6 +85,13 @@ int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, flo
  *   epilogue 3: epilogue 1 followed by ToImage (models.py:141-146, one colour): aux_out (B,H,W) = tanh(sum_c aux_in[c]*y[c]);
  *               aux_in = the N colour weights.  y / rnorm may be NULL (inference: the activation is never written).
  *               Only where ngan_conv3x3_epilogue_fused(...) returns 1. */
+/* Precision 3 (bilinear x2 folded into the weights): the one-pixel border ring of the output is written by a second, small kernel.
+ * By default ngan_conv3x3_fwd / _fwd_ex launch it themselves.  ngan_conv3x3_split_border(1) (returns the previous setting) makes
+ * them launch the main kernel only; the caller then follows each such call with ngan_conv3x3_up2_border on the same stream (the
+ * Python layer does, so that a per-call timer around ngan_conv3x3_fwd brackets exactly one kernel). */
+int ngan_conv3x3_split_border(int on);
+int ngan_conv3x3_up2_border(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
+                            int B, int H, int W, int K, int N, int epilogue, float slope, float eps, void* stream);
 int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision);
 int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                         const float* aux_in, const float* aux_rn, float* aux_out,

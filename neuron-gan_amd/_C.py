@@ -52,6 +52,7 @@ SIGNATURES = {
     "ngan_conv3x3_wgrad_reduce_many": [_P, _I, _P],
     "ngan_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
     "ngan_augment_batch": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ngan_conv3x3_up2_border": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "ngan_first_block_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P],
     "ngan_first_block_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ngan_first_block_dx": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -63,6 +64,7 @@ NON_STATUS = {
     "ngan_augment_workspace_bytes": ([_I, _I], _Z),
     "ngan_first_block_workspace_floats": ([_I, _I, _I], _Z),
     "ngan_first_block_table_floats": ([_I], _Z),
+    "ngan_conv3x3_split_border": ([_I], _I),
     "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
     "ngan_conv3x3_uses_bf16x3": ([_I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_epilogue_fused": ([_I, _I, _I, _I, _I, _I, _I, _I, _I], _I),
@@ -90,6 +92,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
+        handle.ngan_conv3x3_split_border(1)     # this layer launches the folded-bilinear border kernel itself (ops._run_conv)
         _lib = handle
     return _lib
 

@@ -965,15 +965,25 @@ int launch_up2f(ConvArgs a, hipStream_t s) {
     if (grid > n_tiles) grid = n_tiles;
     grid &= ~7;
     if (grid < 8) grid = 8;
+    hipLaunchKernelGGL((conv3x3_up2f_kernel<KG, EPI>), dim3(grid), dim3(256), 0, s, a, n_tiles);
+    return ngan::launch_status("ngan_conv3x3_fwd(bilinear folded)");
+}
+
+template <int KG, int EPI>
+int launch_up2_border(const ConvArgs& a, hipStream_t s) {
     constexpr int NSTEP = KG == 1 ? 5 : 9;
     const float* wraw = a.wp + 4 * (NSTEP * 2 * 256);           // the scaled OIHW weights behind the four folded sets
-    hipLaunchKernelGGL((conv3x3_up2f_kernel<KG, EPI>), dim3(grid), dim3(256), 0, s, a, n_tiles);
-    int st = ngan::launch_status("ngan_conv3x3_fwd(bilinear folded)");
-    if (st) return st;
     const int nborder = 2 * a.W + 2 * (a.H - 2);
     hipLaunchKernelGGL((conv3x3_up2_border_kernel<EPI, KG * 16>), dim3(ngan::ceil_div(nborder, 16), a.B), dim3(256), 0, s, a, wraw);
-    return ngan::launch_status("ngan_conv3x3_fwd(bilinear border)");
+    return ngan::launch_status("ngan_conv3x3_up2_border");
 }
+
+int dispatch_up2_border(const ConvArgs& a, int epilogue, hipStream_t s) {
+    if (a.K == 16) return epilogue ? launch_up2_border<1, EPI_LRELU_PN>(a, s) : launch_up2_border<1, EPI_NONE>(a, s);
+    return epilogue ? launch_up2_border<2, EPI_LRELU_PN>(a, s) : launch_up2_border<2, EPI_NONE>(a, s);
+}
+
+bool g_split_border = false;    // ngan_conv3x3_split_border
 
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 int launch_persist(ConvArgs a, hipStream_t s) {
@@ -1658,8 +1668,10 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
         if (precision == 3) {
             NGAN_REQUIRE((epilogue == EPI_NONE || epilogue == EPI_LRELU_PN) && out_mode == 0, NGAN_ERR_ARG,
                          "conv3x3_fwd: the folded bilinear kernel has epilogues 0 and 1");
-            if (K == 16) return epilogue ? launch_up2f<1, EPI_LRELU_PN>(a, s) : launch_up2f<1, EPI_NONE>(a, s);
-            return epilogue ? launch_up2f<2, EPI_LRELU_PN>(a, s) : launch_up2f<2, EPI_NONE>(a, s);
+            const int st = K == 16 ? (epilogue ? launch_up2f<1, EPI_LRELU_PN>(a, s) : launch_up2f<1, EPI_NONE>(a, s))
+                                   : (epilogue ? launch_up2f<2, EPI_LRELU_PN>(a, s) : launch_up2f<2, EPI_NONE>(a, s));
+            if (st || g_split_border) return st;      // split mode: the caller launches ngan_conv3x3_up2_border itself
+            return dispatch_up2_border(a, epilogue, s);
         }
         if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, precision, s)
                                     : dispatch_persist<1, 2>(a, resample, epilogue, out_mode, precision, s);
@@ -1679,6 +1691,22 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
     }
     if (st || epilogue != EPI_PN_BWD) return st;
     return ngan_lrelu_pixelnorm_bwd(y, nullptr, aux_in, aux_rn, y, (long)B * H * W * (out_mode ? 4 : 1), N, slope, stream);
+}
+
+extern "C" int ngan_conv3x3_split_border(int on) {
+    const int prev = g_split_border ? 1 : 0;
+    g_split_border = on != 0;
+    return prev;
+}
+
+extern "C" int ngan_conv3x3_up2_border(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
+                                       int B, int H, int W, int K, int N, int epilogue, float slope, float eps, void* stream) {
+    NGAN_REQUIRE(x && packed && y, NGAN_ERR_ARG, "conv3x3_up2_border: null pointer");
+    NGAN_REQUIRE(ngan_conv3x3_uses_bf16x3(B, H, W, K, N, NGAN_RESAMPLE_UP2, 1) == 3, NGAN_ERR_SHAPE,
+                 "conv3x3_up2_border: B=%d H=%d W=%d K=%d N=%d is not a folded-bilinear (precision 3) shape", B, H, W, K, N);
+    NGAN_REQUIRE(epilogue == EPI_NONE || (epilogue == EPI_LRELU_PN && rnorm), NGAN_ERR_ARG, "conv3x3_up2_border: epilogue %d", epilogue);
+    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, 0, 0, slope, eps, nullptr, nullptr, nullptr};
+    return dispatch_up2_border(a, epilogue, (hipStream_t)stream);
 }
 
 extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,

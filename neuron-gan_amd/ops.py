@@ -209,8 +209,10 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope):
     y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32)
     rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if epilogue else None
     prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
-    _C.call("ngan_conv3x3_fwd", x, _packed(weight, 0, scale, prec), bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0,
-            float(slope), PIXELNORM_EPS, prec)
+    packed = _packed(weight, 0, scale, prec)
+    _C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0, float(slope), PIXELNORM_EPS, prec)
+    if prec == 3:      # bilinear x2 folded into the weights: the border ring is a launch of its own (include/ngan.h, split mode)
+        _C.call("ngan_conv3x3_up2_border", x, packed, bias, y, rn, b, h, w, cin, cout, epilogue, float(slope), PIXELNORM_EPS)
     return y, rn
 
 

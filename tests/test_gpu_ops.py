@@ -195,6 +195,38 @@ def test_pixelnorm_handoff_matches_unfused(ngan, case, conv_precision):
         assert ok, (name, info)
 
 
+def test_folded_bilinear_border_modes(ngan):
+    """precision 3 through the C ABI: by default ngan_conv3x3_fwd writes the border ring itself; in split mode (what the Python
+    layer uses) the ring is left to ngan_conv3x3_up2_border.  Both must give the same tensor as the operator."""
+    ops, C = ngan.ops, ngan._C
+    ops.set_conv_precision("bf16x3")
+    try:
+        B, H, W, K, N = 2, 128, 256, 16, 16
+        prec = C.conv3x3_uses_bf16x3(B, H, W, K, N, 2, 1)
+        assert prec == 3
+        torch.manual_seed(2)
+        x = torch.randn(B, H // 2, W // 2, K, device=DEV)
+        w = torch.randn(N, K, 3, 3, device=DEV)
+        bias = torch.randn(N, device=DEV)
+        y_ref, rn_ref = ops._run_conv(x, w, bias, 2, 0.1, 1, SLOPE)
+        packed = ops._packed(w, 0, 0.1, prec)
+        y = torch.full_like(y_ref, float("nan"))
+        rn = torch.full_like(rn_ref, float("nan"))
+        assert C.lib().ngan_conv3x3_split_border(0) == 1        # the Python layer runs in split mode
+        try:
+            C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, B, H, W, K, N, 2, 1, 0, SLOPE, 1e-8, prec)
+        finally:
+            C.lib().ngan_conv3x3_split_border(1)
+        assert torch.equal(y, y_ref) and torch.equal(rn, rn_ref)
+        y.fill_(float("nan"))
+        C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, B, H, W, K, N, 2, 1, 0, SLOPE, 1e-8, prec)     # split: ring untouched
+        assert torch.isnan(y[:, 0]).all() and torch.isnan(y[:, :, 0]).all() and not torch.isnan(y[:, 1:-1, 1:-1]).any()
+        C.call("ngan_conv3x3_up2_border", x, packed, bias, y, rn, B, H, W, K, N, 1, SLOPE, 1e-8)
+        assert torch.equal(y, y_ref)
+    finally:
+        ops.set_conv_precision("f32")
+
+
 FIRST_BLOCK_CASES = [
     # B, H, W of the image, FromImage channels C, conv outputs N, pooled on load, biases
     (2, 64, 64, 16, 16, False, True),

@@ -35,7 +35,10 @@ if a.op == "fwd":
     oh, ow = (2 * a.H, 2 * a.W) if a.out else (a.H, a.W)
     y = torch.empty(a.B, oh, ow, a.N, device=dev)
     rn = torch.empty(a.B, a.H, a.W, device=dev)
-    run = lambda: C.call("ngan_conv3x3_fwd", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.res, a.epi, a.out, 0.2, 1e-8, prec)
+    def run():
+        C.call("ngan_conv3x3_fwd", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.res, a.epi, a.out, 0.2, 1e-8, prec)
+        if prec == 3:      # folded bilinear: the border ring is its own launch in the Python layer's split mode (include/ngan.h)
+            C.call("ngan_conv3x3_up2_border", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.epi, 0.2, 1e-8)
 else:
     g = torch.randn(a.B, a.H, a.W, a.N, device=dev)
     gw = torch.empty(a.N, a.K, 3, 3, device=dev)
