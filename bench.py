@@ -1,54 +1,113 @@
-"""Benchmark of the PGGAN / WGAN-GP training step on MI355X (contract: see the task brief / DESIGN.md).
+"""Benchmark of the PGGAN / WGAN-GP training step on MI355X (contract: see the task brief / DESIGN.md section 5).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # starts the N rank processes itself when N > 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one full iteration of the reference's inner loop (train.py:357-385): D step (W loss + drift + gradient
 penalty, backward, Adam) then G step (loss, backward, Adam), n_critic = 1, at the 512x512 final stage (alpha = 1),
-batch 16 per GPU, fp32, synthetic reals 2*U[0,1)-1 already resident in HBM and unit-sphere latents drawn on the GPU.
+batch 16 per GPU, synthetic reals 2*U[0,1)-1 already resident in HBM and unit-sphere latents drawn on the GPU.
+
+The headline `value` is measured in the reference's arithmetic: fp32 storage, fp32 accumulation and EXACT fp32 products
+(v_mfma_f32_16x16x4_f32; the reference computes in the default dtype, train.py:136-144), `dtype: "f32"`.  The faster split-bf16
+convolution mode (3 bf16 MFMAs per fp32 product group, 16-bit-mantissa operands) is timed by the same protocol right afterwards
+and reported as the labelled sub-record `"bf16x3"` of the same JSON line, with the relative error it shows against the fp32 mode
+on identical weights and draws (`max_rel_err`).  It is never the headline.
+
 Rank 0 prints ONE JSON line: images/s over all ranks, plus
-  roofline     -- the dominant kernel (the conv template instance with the largest summed time over ngan_conv3x3_fwd and
-                  ngan_conv3x3_fwd_ex) timed with HIP events on its launch stream: achieved = algorithmic bytes (split-bf16
-                  instances: HBM roof, 8 TB/s) or flops (exact-fp32 instances: fp32 MFMA roof, 157.3 TF) of those launches / their
-                  summed duration; traffic = HBM bytes per launch from the committed PMC summary (profiles/, tools/measure_round.sh)
+  roofline     -- the dominant kernel = the conv template instance (forward / input-gradient / weight-gradient entry points) with the
+                  largest summed time, timed with HIP events on its launch stream: exact-fp32 instances against the fp32 MFMA
+                  roof (157.3 TFLOP/s: achieved = 2*9*K*N*pixels of its launches / their summed duration), split-bf16 instances
+                  against HBM (8 TB/s: achieved = algorithmic bytes / duration); traffic = HBM bytes per launch from the
+                  committed PMC summary (profiles/, tools/measure_round.sh)
   cpu_baseline -- the CPU oracle (oracle/pggan_oracle.py, a port of the reference's path) timed on this host's cores on a
-                  bounded sample of the same workload (N = 1 only).
+                  bounded sample of the same workload at the same batch (N = 1 only), with the CPU model string.
+
+Multi-GPU: `python bench.py --gpus N` without a launcher environment starts N child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set) BEFORE anything touches the GPU -- the parent never imports torch -- and exits with their worst exit code.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from __graft_entry__ import load_package  # noqa: E402
 
 G_WIDTHS = [128, 64, 32, 32, 16, 16]
 D_WIDTHS = [16, 16, 32, 32, 64, 128]
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (about 6.3 TB/s is achievable with a float4 copy)
+PROFILE_TAG = "r02"            # profiles/<tag>_traffic_<precision>.json holds the PMC traffic per kernel
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: N rank processes from the bare command
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start n copies of this script, one per rank, and wait.  Nothing in this process has initialised HIP (torch is not even
+    imported), so the children are ordinary fork+exec processes; rank 0's stdout is the JSON line."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, NGAN_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    worst = 0
+    try:
+        for p in procs:
+            rc = p.wait()
+            if rc != 0 and worst == 0:
+                worst = rc
+                for q in procs:             # one rank died: the others would wait for it in a collective
+                    if q.poll() is None:
+                        q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            q.terminate()
+        raise
+    return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-launch probe
+# ---------------------------------------------------------------------------------------------------------------------
 class ConvProbe:
-    """HIP-event timing of ngan_conv3x3_fwd launches, bucketed by kernel template instance."""
+    """HIP-event timing of the 3x3-conv entry points (forward / input gradient: ngan_conv3x3_fwd, _fwd_ex; weight gradient:
+    ngan_conv3x3_wgrad), bucketed by the kernel template instance each call dispatches to."""
 
-    def __init__(self, name_of):
-        self.records = []  # (key, flops, e0, e1)
-        self.name_of = name_of
+    def __init__(self, C):
+        self.records = []  # (key, flops, bytes, e0, e1)
+        self.C = C
 
     @staticmethod
     def wants(name, args):
-        return name in ("ngan_conv3x3_fwd", "ngan_conv3x3_fwd_ex")
+        return name in ("ngan_conv3x3_fwd", "ngan_conv3x3_fwd_ex", "ngan_conv3x3_wgrad")
 
     def add(self, name, args, e0, e1):
+        if name == "ngan_conv3x3_wgrad":
+            # (x, g, gw, workspace, B, H, W, Cin, Cout, resample, scale, accumulate, precision): the contraction runs over pixels;
+            # bytes = the input read once (1/4 of the pixels behind a bilinear x2, 4x behind an avg-pool) + the output gradient
+            b, h, w, cin, cout, resample = args[4:10]
+            key = self.C.conv3x3_wgrad_kernel_name(b, h, w, cin, cout, resample, args[12])
+            pix = b * h * w
+            src = pix * (4 if resample == 1 else 0.25 if resample == 2 else 1)
+            self.records.append((key, 2.0 * 9 * cin * cout * pix, 4.0 * (src * cin + pix * cout), e0, e1))
+            return
         o = 8 if name == "ngan_conv3x3_fwd_ex" else 5          # fwd_ex carries three more pointers (include/ngan.h)
         b, h, w, k, n, resample, epilogue, out_mode = args[o:o + 8]
-        key = self.name_of(b, h, w, k, n, resample, epilogue, out_mode, args[o + 10])   # the template instance, as rocprofv3 names it
+        key = self.C.conv3x3_kernel_name(b, h, w, k, n, resample, epilogue, out_mode, args[o + 10])   # the template instance, as rocprofv3 names it
         # algorithmic work of one launch: 2*9*K*N flop per output pixel; bytes = the input read once
         # (K channels per source pixel; 1/4 of the pixels for bilinear input, 4x for pooled), the output written once
         # (4x the pixels for the pool-adjoint store; not at all when the ToImage epilogue runs without a stored activation), the
@@ -76,10 +135,19 @@ class ConvProbe:
             d[2] += e0.elapsed_time(e1) * 1e-3
             d[3] += nbytes
         return {k: {"launches": v[0], "flops": v[1], "seconds": v[2], "avg_us": v[2] / v[0] * 1e6, "tflops": v[1] / v[2] / 1e12,
-                    "gbs": v[3] / v[2] / 1e9} for k, v in per.items() if v[2] > 0}
+                    "gbs": v[3] / v[2] / 1e9, "bytes_per_launch": v[3] / v[0], "flops_per_launch": v[1] / v[0]}
+                for k, v in per.items() if v[2] > 0}
+
+
+def is_split_bf16_instance(name):
+    """does this kernel template instance compute its products on the bf16 MFMA (HBM is then the binding roof)?"""
+    if "mid_kernel" in name or "up2f" in name or "wgrad_bf16x3" in name:
+        return True
+    return "persist" in name and name.rstrip(">").endswith(", 1")
 
 
 def build_nets(pkg, res, alpha, device):
+    import torch
     torch.manual_seed(1)  # BASELINE.md section 3: weights from torch.manual_seed(1)
     G = pkg.models.Generator_PG(G_WIDTHS, image_size_init=16)
     D = pkg.models.Discriminator_PG(D_WIDTHS, image_size_init=16)
@@ -89,8 +157,22 @@ def build_nets(pkg, res, alpha, device):
     return G.to(device), D.to(device)
 
 
-def cpu_baseline(res, alpha, sample_batch, budget_s=12.0):
-    """Time the CPU oracle (port of the reference path) on this host; bounded sample of the same workload."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(res, alpha, batch, budget_s=25.0, max_iters=4):
+    """Time the CPU oracle (port of the reference path) on this host at the bench's own batch; bounded sample of the same workload."""
+    import torch
+    from __graft_entry__ import load_package
     from oracle import pggan_oracle as O
     torch.manual_seed(1)
     pkg = load_package()
@@ -109,56 +191,24 @@ def cpu_baseline(res, alpha, sample_batch, budget_s=12.0):
     torch.manual_seed(123)
     done, t0 = 0, time.perf_counter()
     while True:
-        x = torch.rand(sample_batch, 1, res, res) * 2 - 1
-        z = [O.sample_latent_vec((sample_batch, 512)) for _ in range(3)]
-        O.train_step(pg, spec, pd, spec, og, od, x, z[0], z[1], torch.rand(sample_batch, 1, 1, 1), z[2])
+        x = torch.rand(batch, 1, res, res) * 2 - 1
+        z = [O.sample_latent_vec((batch, 512)) for _ in range(3)]
+        O.train_step(pg, spec, pd, spec, og, od, x, z[0], z[1], torch.rand(batch, 1, 1, 1), z[2])
         done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 8:
+        if done >= max_iters or el + el / done > budget_s:     # stop when the next iteration would overrun the budget
             break
-    return {"value": sample_batch * done / el, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{done} full iteration(s) of the oracle at {res}x{res}, batch {sample_batch}, fp32, {cores} torch threads, {el:.1f} s"}
+    return {"value": batch * done / el, "unit": "images/s", "cores": cores, "cpu_model": cpu_model_name(), "kind": "port",
+            "sample": f"{done} full iteration(s) of the oracle at {res}x{res}, batch {batch}, fp32, {cores} torch threads, {el:.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--alpha", type=float, default=1.0)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
-    ap.add_argument("--graph", type=int, default=-1, help="1: replay a captured HIP graph, 0: eager, -1: auto")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
-                    help="conv arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate) where available")
-    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient all-reduce even with one rank (path test)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-probe", action="store_true", help="do not time the dominant kernel with HIP events")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    # rehearsal on a one-GPU box: NGAN_REHEARSAL_BACKEND=gloo runs every rank on cuda:0 with the collectives staged through the
-    # host (same step driver, same segmented graph capture; the numbers mean nothing).  The real run is RCCL, one rank per GPU.
-    rehearsal = os.environ.get("NGAN_REHEARSAL_BACKEND", "")
-    device = torch.device("cuda", 0 if rehearsal else local_rank)
-    torch.cuda.set_device(device)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
-            os.environ.setdefault(k, v)          # `python bench.py --force-dist` without a launcher: a one-rank group
-        if rehearsal:
-            dist.init_process_group(rehearsal)
-        else:
-            dist.init_process_group("nccl", device_id=device)
-
-    pkg = load_package()
-    pkg._C.lib()
-    pkg.ops.set_conv_precision(args.precision)
+# ---------------------------------------------------------------------------------------------------------------------
+# one timed run in one arithmetic mode
+# ---------------------------------------------------------------------------------------------------------------------
+def run_mode(pkg, args, precision, device, world, rank, use_dist):
+    import torch
+    import torch.distributed as dist
+    pkg.ops.set_conv_precision(precision)
     G, D = build_nets(pkg, args.res, args.alpha, device)
     trainer = pkg.train.PGGANTrainer(G, D, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001,
                                      device_latents=True)
@@ -169,9 +219,10 @@ def main():
     pool = [(torch.rand(args.batch, 1, args.res, args.res) * 2 - 1).to(device) for _ in range(4)]
     torch.cuda.manual_seed(1000 + rank)
 
-    # launch mode: HIP-graph replay of the whole iteration on one GPU (captured once), eager under torchrun
-    use_graph = args.graph != 0   # one graph on a single GPU; three graphs with eager all-reduces between them under torchrun
-    probe = None if args.no_probe else ConvProbe(pkg._C.conv3x3_kernel_name)
+    # launch mode: HIP-graph replay of the whole iteration on one GPU (captured once); three graphs with the eager gradient
+    # exchanges between them when there is a process group
+    use_graph = args.graph != 0
+    probe = None if args.no_probe else ConvProbe(pkg._C)
 
     def step(i):
         if use_graph:
@@ -181,7 +232,7 @@ def main():
 
     if use_graph:
         try:
-            trainer.capture(pool[0], warmup=max(1, args.warmup))
+            trainer.capture(pool[0], warmup=max(1, min(args.warmup, 3)))
         except Exception as e:  # capture is an optimisation, never a requirement
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             use_graph = False
@@ -218,55 +269,181 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    out = {"elapsed": elapsed, "launch": ("hip-graph replay" + (" (3 segments, eager gradient exchange between)" if use_dist else ""))
+           if use_graph else "eager", "roofline": None, "conv_family": None}
+    if rank == 0 and probe is not None and probe.records:
+        summ = probe.summary()
+        dom = max(summ, key=lambda k: summ[k]["seconds"])
+        d = summ[dom]
+        # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3
+        # passes over this same command; committed summary, see profiles/README.md).  null if no summary for this mode.
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_traffic_{precision}.json")
+        if os.path.exists(tfile) and args.res == 512 and args.batch == 16:
+            with open(tfile) as fh:
+                tk = json.load(fh)["kernels"].get(dom)
+            if tk:
+                traffic, traffic_src = tk["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
+        common = {"kernel": dom, "traffic": traffic, "traffic_source": traffic_src, "launches": d["launches"], "avg_launch_us": d["avg_us"],
+                  "algorithmic_bytes_per_launch": d["bytes_per_launch"], "algorithmic_flops_per_launch": d["flops_per_launch"], "timing": probe_note}
+        if is_split_bf16_instance(dom):   # ~5x the fp32 MFMA rate, so HBM is the binding roof
+            out["roofline"] = dict({"bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["gbs"] / PEAK_HBM_GBS,
+                                    "fp32_equivalent_tflops": d["tflops"]}, **common)
+        else:
+            out["roofline"] = dict({"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "gbs": d["gbs"]}, **common)
+        tot_f = sum(v["flops"] for v in summ.values())
+        tot_s = sum(v["seconds"] for v in summ.values())
+        out["conv_family"] = {"tflops": tot_f / tot_s / 1e12, "seconds_per_step": tot_s / args.steps,
+                              "instances": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
+                                                "launches_per_step": v["launches"] / args.steps} for k, v in summ.items()}}
+    del trainer, G, D, pool
+    torch.cuda.empty_cache()
+    return out
+
+
+def precision_gap(pkg, args, device):
+    """Relative error of the split-bf16 mode against the exact-fp32 mode on identical weights, reals, latents and epsilon: the three
+    losses, the scores, the gradient penalty and the two nets' flat gradients (relative L2) of one iteration's forward/backward passes."""
+    import torch
+    out = {}
+    got = {}
+    for precision in ("f32", "bf16x3"):
+        pkg.ops.set_conv_precision(precision)
+        G, D = build_nets(pkg, args.res, args.alpha, device)
+        tr = pkg.train.PGGANTrainer(G, D, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001)
+        gen = torch.Generator().manual_seed(4242)
+        b = min(args.batch, 8)
+        real = (torch.rand(b, 1, args.res, args.res, generator=gen) * 2 - 1).to(device)
+        zs = []
+        for _ in range(3):
+            z = torch.randn(b, 512, generator=gen).clamp(-5, 5)
+            zs.append((z / z.norm(dim=1, keepdim=True)).to(device))
+        eps = torch.rand(b, 1, 1, 1, generator=gen).to(device)
+        st = tr.d_compute(real, zs[0], zs[1], eps)
+        gd = tr.flat_d.grad.clone()
+        st.update(tr.g_compute(real, zs[2]))
+        gg = tr.flat_g.grad.clone()
+        torch.cuda.synchronize()
+        got[precision] = ({k: float(v) for k, v in st.items()}, gd, gg)
+        del tr, G, D
+    a, b = got["f32"], got["bf16x3"]
+    for k in a[0]:
+        out[k] = abs(a[0][k] - b[0][k]) / max(abs(a[0][k]), 1e-12)
+    out["D_grad_rel_l2"] = float((a[1] - b[1]).norm() / a[1].norm())
+    out["G_grad_rel_l2"] = float((a[2] - b[2]).norm() / a[2].norm())
+    return max(out.values()), out
+
+
+def launch_check(world, rank):
+    """`--launch-check`: the launcher path without a GPU -- a gloo group over the started ranks, one all-reduce, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1)
+    dist.all_reduce(t)
     if rank == 0:
-        from oracle import pggan_oracle as O
+        print(json.dumps({"launch_check": True, "n_gpus": world, "world_size_observed": dist.get_world_size(), "sum_of_ones": float(t.item()),
+                          "backend": "gloo"}), flush=True)
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--alpha", type=float, default=1.0)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay a captured HIP graph, 0: eager, -1: auto")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="conv arithmetic of the headline: exact fp32 MFMA (the reference's arithmetic), or split-bf16 "
+                         "(3 bf16 MFMAs per product, fp32 accumulate) where available")
+    ap.add_argument("--sub-record", type=int, default=-1, help="1: also time the split-bf16 mode and report it as the sub-record "
+                                                               "'bf16x3'; 0: do not; -1: only on one GPU")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient exchange even with one rank (path test)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="do not time the dominant kernel with HIP events")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, all-reduce over gloo on the CPU, print one line (no GPU)")
+    args = ap.parse_args()
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        # the bare command: become the launcher.  Nothing GPU-related has happened in this process (torch is not imported).
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_check:
+        return launch_check(world, rank)
+
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+
+    # rehearsal on a one-GPU box: NGAN_REHEARSAL_BACKEND=gloo runs every rank on cuda:0 with the collectives staged through the
+    # host (same step driver, same segmented graph capture; the numbers mean nothing).  The real run is RCCL, one rank per GPU.
+    rehearsal = os.environ.get("NGAN_REHEARSAL_BACKEND", "")
+    if not rehearsal and world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                         f"(NGAN_REHEARSAL_BACKEND=gloo rehearses the multi-rank path on one GPU)")
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
+    torch.cuda.set_device(device)
+    use_dist = world > 1 or args.force_dist
+    backend = None
+    if use_dist:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)          # `python bench.py --force-dist` without a launcher: a one-rank group
+        if rehearsal:
+            dist.init_process_group(rehearsal)
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        backend = dist.get_backend()
+
+    pkg = load_package()
+    pkg._C.lib()
+    head = run_mode(pkg, args, args.precision, device, world, rank, use_dist)
+    want_sub = args.sub_record == 1 or (args.sub_record == -1 and world == 1 and not args.force_dist)
+    sub = gap = None
+    if want_sub and args.precision == "f32":
+        sub = run_mode(pkg, args, "bf16x3", device, world, rank, use_dist)
+        if rank == 0:
+            gap = precision_gap(pkg, args, device)
+        pkg.ops.set_conv_precision("f32")
+
+    if rank == 0:
+        wm = pkg.workmodel
         images = args.batch * world * args.steps
-        value = images / elapsed
-        fg, fd = O.forward_flops(G_WIDTHS, D_WIDTHS, 16, args.res, 512, args.alpha)
-        w_alg = 5 * fg + 14 * fd  # algorithmic flops per image per iteration
+        value = images / head["elapsed"]
+        w_alg = wm.iteration_flops(G_WIDTHS, D_WIDTHS, 16, args.res, 512, args.alpha)   # SURVEY.md 8(d): FLOP per image per iteration
+        e_alg = wm.iteration_io_elements(G_WIDTHS, D_WIDTHS, 16, args.res, 512, args.alpha)
+        dtype_of = {"f32": "f32", "bf16x3": "f32 storage/accumulate; 3x3 convs on split-bf16 MFMA (bf16x3, hi+lo operands)"}
         out = {"metric": "images/sec (G+D step incl. GP) at 512x512", "value": value, "unit": "images/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.precision == "f32" else "f32 storage/accumulate; 3x3 convs on split-bf16 MFMA (bf16x3, hi+lo operands)",
-               "data": "synthetic",
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": dtype_of[args.precision], "data": "synthetic",
                "config": {"workload": f"{args.res}x{args.res} stage, alpha={args.alpha}, batch {args.batch}/GPU, WGAN-GP lambda=10, "
                                       f"drift 0.001, n_critic=1, Adam(1e-4, 0.5, 0.999), widths G{G_WIDTHS} D{D_WIDTHS}",
                           "global_batch": args.batch * world, "resolution": args.res, "parallelism": f"dp{world}",
-                          "launch": ("hip-graph replay" + (" (3 segments, eager all-reduce between)" if use_dist else "")) if use_graph else "eager", "conv_precision": args.precision},
-               "step_tflops": value * w_alg / 1e12, "step_frac_of_fp32_mfma_peak": value * w_alg / 1e12 / world / PEAK_FP32_MFMA_TFLOPS}
-        if probe is not None and probe.records:
-            summ = probe.summary()
-            dom = max(summ, key=lambda k: summ[k]["seconds"])
-            d = summ[dom]
-            # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3
-            # passes over this same command; committed summary, see profiles/README.md).  null if no summary for this mode.
-            traffic, traffic_src = None, None
-            tfile = os.path.join(ROOT, "profiles", f"r01_e_traffic_{args.precision}.json")
-            if os.path.exists(tfile) and args.res == 512 and args.batch == 16:
-                with open(tfile) as fh:
-                    tk = json.load(fh)["kernels"].get(dom)
-                if tk:
-                    traffic, traffic_src = tk["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
-            if "mid_kernel" in dom or "up2f" in dom or ("persist" in dom and dom.rstrip(">").endswith(", 1")):   # split-bf16 instance: ~5x the fp32 MFMA rate, so HBM is the binding roof
-                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                                   "algorithmic_bytes_per_launch": d["gbs"] * 1e9 * d["avg_us"] * 1e-6, "launches": d["launches"],
-                                   "avg_launch_us": d["avg_us"], "timing": probe_note,
-                                   "fp32_equivalent_tflops": d["tflops"]}
-            else:
-                out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                                   "traffic_source": traffic_src, "launches": d["launches"], "avg_launch_us": d["avg_us"], "timing": probe_note}
-            tot_f = sum(v["flops"] for v in summ.values())
-            tot_s = sum(v["seconds"] for v in summ.values())
-            out["conv_family"] = {"tflops": tot_f / tot_s / 1e12, "seconds_per_step": tot_s / args.steps,
-                                  "instances": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
-                                                    "launches_per_step": v["launches"] / args.steps} for k, v in summ.items()}}
-        else:
-            out["roofline"] = None
+                          "launch": head["launch"], "conv_precision": args.precision,
+                          "world_size_observed": dist.get_world_size() if use_dist else 1, "backend": backend},
+               "step_tflops": value * w_alg / 1e12,
+               "step_frac_of_fp32_mfma_peak": (value * w_alg / 1e12 / world / PEAK_FP32_MFMA_TFLOPS) if args.precision == "f32" else None,
+               "step_algorithmic_gbs": value * e_alg * 4 / 1e9 / world,
+               "roofline": head["roofline"], "conv_family": head["conv_family"]}
+        if sub is not None:
+            v2 = images / sub["elapsed"]
+            out["bf16x3"] = {"label": "split-bf16 convolution mode (NOT the headline: 16-bit-mantissa operands, narrower than the reference's fp32)",
+                             "value": v2, "unit": "images/s", "ms_per_step": sub["elapsed"] / args.steps * 1e3, "dtype": dtype_of["bf16x3"],
+                             "max_rel_err": gap[0], "rel_err_vs_f32": gap[1], "step_fp32_equivalent_tflops": v2 * w_alg / 1e12,
+                             "step_algorithmic_gbs": v2 * e_alg * 4 / 1e9, "step_frac_of_hbm_peak": v2 * e_alg * 4 / 1e9 / PEAK_HBM_GBS,
+                             "roofline": sub["roofline"], "conv_family": sub["conv_family"]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.res, args.alpha, sample_batch=min(args.batch, 4))
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(args.res, args.alpha, batch=args.batch)
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

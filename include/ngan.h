@@ -34,6 +34,8 @@ extern "C" {
 #define NGAN_RESAMPLE_NONE 0
 #define NGAN_RESAMPLE_POOL2 1
 #define NGAN_RESAMPLE_UP2 2
+/* flags of ngan_conv3x3_fwd / ngan_conv3x3_fwd_ex (per call; the library keeps no mutable global state) */
+#define NGAN_CONV_SKIP_BORDER 1   /* precision 3 only: do not launch the border-ring kernel, the caller follows up with ngan_conv3x3_up2_border */
 
 const char* ngan_version(void);
 const char* ngan_last_error(void);
@@ -74,7 +76,7 @@ int ngan_conv3x3_pack_many(const void* table, int n_entries, long total_elements
  * K = contraction channels, N = output channels (N <= 128 per call). */
 int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                      int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                     float slope, float eps, int precision, void* stream);
+                     float slope, float eps, int precision, int flags, void* stream);
 
 /* The same kernels with two more fused epilogues (what the hand-scheduled first-order passes of train.py:365, 384 use):
  *   epilogue 2: the call computes an input gradient g (packed = flipped weights) and applies the backward of the
@@ -86,22 +88,23 @@ int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, flo
  *               aux_in = the N colour weights.  y / rnorm may be NULL (inference: the activation is never written).
  *               Only where ngan_conv3x3_epilogue_fused(...) returns 1. */
 /* Precision 3 (bilinear x2 folded into the weights): the one-pixel border ring of the output is written by a second, small kernel.
- * By default ngan_conv3x3_fwd / _fwd_ex launch it themselves.  ngan_conv3x3_split_border(1) (returns the previous setting) makes
- * them launch the main kernel only; the caller then follows each such call with ngan_conv3x3_up2_border on the same stream (the
- * Python layer does, so that a per-call timer around ngan_conv3x3_fwd brackets exactly one kernel). */
-int ngan_conv3x3_split_border(int on);
+ * By default ngan_conv3x3_fwd / _fwd_ex launch it themselves.  With flags & NGAN_CONV_SKIP_BORDER a call launches the main kernel
+ * only and the caller follows it with ngan_conv3x3_up2_border on the same stream (the Python layer does, so that a per-call timer
+ * around ngan_conv3x3_fwd brackets exactly one kernel).  The choice is per call: nothing is remembered between calls. */
 int ngan_conv3x3_up2_border(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                             int B, int H, int W, int K, int N, int epilogue, float slope, float eps, void* stream);
 int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision);
 int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                         const float* aux_in, const float* aux_rn, float* aux_out,
                         int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                        float slope, float eps, int precision, void* stream);
+                        float slope, float eps, int precision, int flags, void* stream);
 
 /* name of the kernel template instance ngan_conv3x3_fwd dispatches to for these arguments, as rocprofv3 prints it
  * (profiling aid: lets bench.py label its HIP-event timings with the same names as the kernel trace) */
 int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision,
                              char* buf, int len);
+/* the same for ngan_conv3x3_wgrad (its main kernel; the slab reduction is a second kernel) */
+int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int resample, int precision, char* buf, int len);
 
 /* weight gradient (ATen convolution_backward, weight part):
  *   gw[co][ci][ky][kx] = scale * sum_{b,y,x} g[b,y,x,co] * resample(x)[b,y+ky-1,x+kx-1,ci]      gw is OIHW

@@ -12,12 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NGAN_LIB_PATH") or os.path.join(_HERE, "libngan_hip.so")      # (override: A/B runs of kernel variants)
 
 _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+CONV_SKIP_BORDER = 1     # NGAN_CONV_SKIP_BORDER (include/ngan.h): per-call flag of ngan_conv3x3_fwd / _fwd_ex
 
 # name -> argument types (the trailing void* stream included), mirroring include/ngan.h
 SIGNATURES = {
     "ngan_conv3x3_pack_weights": [_P, _P, _I, _I, _I, _F, _I, _P],
-    "ngan_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
-    "ngan_conv3x3_fwd_ex": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
+    "ngan_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _P],
+    "ngan_conv3x3_fwd_ex": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _P],
     "ngan_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "ngan_lrelu_pixelnorm_fwd": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
     "ngan_lrelu_pixelnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
@@ -64,7 +65,7 @@ NON_STATUS = {
     "ngan_augment_workspace_bytes": ([_I, _I], _Z),
     "ngan_first_block_workspace_floats": ([_I, _I, _I], _Z),
     "ngan_first_block_table_floats": ([_I], _Z),
-    "ngan_conv3x3_split_border": ([_I], _I),
+    "ngan_conv3x3_wgrad_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
     "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
     "ngan_conv3x3_uses_bf16x3": ([_I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_epilogue_fused": ([_I, _I, _I, _I, _I, _I, _I, _I, _I], _I),
@@ -92,7 +93,6 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        handle.ngan_conv3x3_split_border(1)     # this layer launches the folded-bilinear border kernel itself (ops._run_conv)
         _lib = handle
     return _lib
 
@@ -155,6 +155,13 @@ def wgrad_workspace_bytes(B, H, W, Cin, Cout) -> int:
 def conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, precision=0) -> str:
     buf = ctypes.create_string_buffer(128)
     if lib().ngan_conv3x3_kernel_name(B, H, W, K, N, resample, epilogue, out_mode, precision, buf, 128) != 0:
+        raise RuntimeError(lib().ngan_last_error().decode())
+    return buf.value.decode()
+
+
+def conv3x3_wgrad_kernel_name(B, H, W, Cin, Cout, resample, precision=0) -> str:
+    buf = ctypes.create_string_buffer(128)
+    if lib().ngan_conv3x3_wgrad_kernel_name(B, H, W, Cin, Cout, resample, precision, buf, 128) != 0:
         raise RuntimeError(lib().ngan_last_error().decode())
     return buf.value.decode()
 

@@ -11,8 +11,9 @@ The directory name carries a hyphen, so it is loaded under the module name `neur
     configs/config.py  module-as-singleton configuration
     train.py           the G/D step driver (flat parameters, fused Adam, data-parallel gradient exchange), epoch driver, CLI
     data.py            device-resident dataset with the reference's augmentation chain as one launch per batch
+    workmodel.py       algorithmic FLOP / byte model of an iteration (what bench.py's roofline figures divide by)
 """
-from . import _C, ops, utils, models, loss_functions, train, data  # noqa: F401
+from . import _C, ops, utils, models, loss_functions, train, data, workmodel  # noqa: F401
 from .configs import config  # noqa: F401
 
 __version__ = "0.1.0"

@@ -983,8 +983,6 @@ int dispatch_up2_border(const ConvArgs& a, int epilogue, hipStream_t s) {
     return epilogue ? launch_up2_border<2, EPI_LRELU_PN>(a, s) : launch_up2_border<2, EPI_NONE>(a, s);
 }
 
-bool g_split_border = false;    // ngan_conv3x3_split_border
-
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 int launch_persist(ConvArgs a, hipStream_t s) {
     a.tiles_x = ngan::ceil_div(a.W, 32);
@@ -1641,8 +1639,9 @@ extern "C" int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, in
 extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                                    const float* aux_in, const float* aux_rn, float* aux_out,
                                    int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                                   float slope, float eps, int precision, void* stream) {
+                                   float slope, float eps, int precision, int flags, void* stream) {
     NGAN_REQUIRE(x && packed && (y || epilogue == EPI_TO_IMAGE), NGAN_ERR_ARG, "conv3x3_fwd: null pointer");
+    NGAN_REQUIRE((flags & ~NGAN_CONV_SKIP_BORDER) == 0, NGAN_ERR_ARG, "conv3x3_fwd: unknown flags 0x%x", flags);
     NGAN_REQUIRE(precision == 0 || precision == ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, 1), NGAN_ERR_ARG,
                  "conv3x3_fwd: precision %d is not available for this shape (ask ngan_conv3x3_uses_bf16x3)", precision);
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_fwd: bad dims B=%d H=%d W=%d", B, H, W);
@@ -1670,7 +1669,7 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
                          "conv3x3_fwd: the folded bilinear kernel has epilogues 0 and 1");
             const int st = K == 16 ? (epilogue ? launch_up2f<1, EPI_LRELU_PN>(a, s) : launch_up2f<1, EPI_NONE>(a, s))
                                    : (epilogue ? launch_up2f<2, EPI_LRELU_PN>(a, s) : launch_up2f<2, EPI_NONE>(a, s));
-            if (st || g_split_border) return st;      // split mode: the caller launches ngan_conv3x3_up2_border itself
+            if (st || (flags & NGAN_CONV_SKIP_BORDER)) return st;      // the caller launches ngan_conv3x3_up2_border itself
             return dispatch_up2_border(a, epilogue, s);
         }
         if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, precision, s)
@@ -1693,12 +1692,6 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
     return ngan_lrelu_pixelnorm_bwd(y, nullptr, aux_in, aux_rn, y, (long)B * H * W * (out_mode ? 4 : 1), N, slope, stream);
 }
 
-extern "C" int ngan_conv3x3_split_border(int on) {
-    const int prev = g_split_border ? 1 : 0;
-    g_split_border = on != 0;
-    return prev;
-}
-
 extern "C" int ngan_conv3x3_up2_border(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                                        int B, int H, int W, int K, int N, int epilogue, float slope, float eps, void* stream) {
     NGAN_REQUIRE(x && packed && y, NGAN_ERR_ARG, "conv3x3_up2_border: null pointer");
@@ -1711,10 +1704,10 @@ extern "C" int ngan_conv3x3_up2_border(const float* x, const float* packed, cons
 
 extern "C" int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                                 int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                                float slope, float eps, int precision, void* stream) {
+                                float slope, float eps, int precision, int flags, void* stream) {
     NGAN_REQUIRE(epilogue == 0 || epilogue == 1, NGAN_ERR_ARG, "conv3x3_fwd: epilogue %d (2 and 3 need ngan_conv3x3_fwd_ex)", epilogue);
     return ngan_conv3x3_fwd_ex(x, packed, bias, y, rnorm, nullptr, nullptr, nullptr, B, H, W, K, N, resample, epilogue, out_mode,
-                               slope, eps, precision, stream);
+                               slope, eps, precision, flags, stream);
 }
 
 extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
@@ -1735,6 +1728,15 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
         snprintf(buf, len, "conv3x3_kernel<%d, %d, %d, %d, %d, %d, %d>", c.mtw, c.wn, c.pgw, c.pcg, out_mode ? 0 : resample,
                  out_mode ? 0 : epilogue, out_mode);
     }
+    return NGAN_OK;
+}
+
+extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int resample, int precision, char* buf, int len) {
+    NGAN_REQUIRE(buf && len > 0, NGAN_ERR_ARG, "conv3x3_wgrad_kernel_name: bad buffer");
+    NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
+                 "conv3x3_wgrad_kernel_name: bad shape");
+    const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
+    snprintf(buf, len, "%s<%d, %d, %d, %d>", precision == 1 ? "wgrad_bf16x3_kernel" : "wgrad_kernel", p.co_s / 16, p.ci_s / 16, resample, p.tw);
     return NGAN_OK;
 }
 

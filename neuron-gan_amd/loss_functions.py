@@ -82,7 +82,9 @@ class D_grad_pen_loss(nn.Module):
 
     def forward(self, real_images, z=None, epsilon=None, x_tilde=None):
         if not self.Lambda > 0:
-            return torch.tensor(0)
+            # the reference returns the integer CPU scalar torch.tensor(0) here (loss_functions.py:179), which only survives being
+            # stacked / accumulated with device tensors by accident; same value, on the images' device
+            return torch.zeros((), device=real_images.device)
         batch_size, device = real_images.size(0), real_images.device
         if x_tilde is None:
             z_latent = _latents(self.generator_net, batch_size, device, z)

@@ -210,8 +210,9 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope):
     rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if epilogue else None
     prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
     packed = _packed(weight, 0, scale, prec)
-    _C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0, float(slope), PIXELNORM_EPS, prec)
-    if prec == 3:      # bilinear x2 folded into the weights: the border ring is a launch of its own (include/ngan.h, split mode)
+    _C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0, float(slope), PIXELNORM_EPS, prec,
+            _C.CONV_SKIP_BORDER if prec == 3 else 0)
+    if prec == 3:      # bilinear x2 folded into the weights: the border ring is a launch of its own (NGAN_CONV_SKIP_BORDER, include/ngan.h)
         _C.call("ngan_conv3x3_up2_border", x, packed, bias, y, rn, b, h, w, cin, cout, epilogue, float(slope), PIXELNORM_EPS)
     return y, rn
 
@@ -231,11 +232,11 @@ def _run_dgrad(g, weight, resample, scale, link=None):
         gx = torch.empty((b, 2 * h, 2 * w, cin), device=g.device, dtype=torch.float32)
         if link is not None and tuple(ay.shape) != tuple(gx.shape):
             raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(gx.shape)}")
-        _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gx, None, ay, arn, None, b, h, w, cout, cin, 0, epi, 1, slope, 0.0, prec)
+        _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gx, None, ay, arn, None, b, h, w, cout, cin, 0, epi, 1, slope, 0.0, prec, 0)
         return gx
     if resample == RES_UP2:
         gfull = torch.empty((b, h, w, cin), device=g.device, dtype=torch.float32)
-        _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gfull, None, None, None, None, b, h, w, cout, cin, 0, EPI_NONE, 0, 0.0, 0.0, prec)
+        _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gfull, None, None, None, None, b, h, w, cout, cin, 0, EPI_NONE, 0, 0.0, 0.0, prec, 0)
         gx = torch.empty((b, h // 2, w // 2, cin), device=g.device, dtype=torch.float32)
         if link is not None:
             if tuple(ay.shape) != tuple(gx.shape):
@@ -247,7 +248,7 @@ def _run_dgrad(g, weight, resample, scale, link=None):
     gx = torch.empty((b, h, w, cin), device=g.device, dtype=torch.float32)
     if link is not None and tuple(ay.shape) != tuple(gx.shape):
         raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(gx.shape)}")
-    _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gx, None, ay, arn, None, b, h, w, cout, cin, 0, epi, 0, slope, 0.0, prec)
+    _C.call("ngan_conv3x3_fwd_ex", g, packed, None, gx, None, ay, arn, None, b, h, w, cout, cin, 0, epi, 0, slope, 0.0, prec, 0)
     return gx
 
 
@@ -412,7 +413,7 @@ class ConvLReLUPNToImage(Function):
         t = torch.empty((b, h, w, 1), device=x.device, dtype=torch.float32)
         prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
         _C.call("ngan_conv3x3_fwd_ex", x, _packed(weight, 0, scale, prec), bias, y, rn, w_img.detach().reshape(-1), None, t,
-                b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, float(slope), PIXELNORM_EPS, prec)
+                b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, float(slope), PIXELNORM_EPS, prec, 0)
         if keep:
             ctx.save_for_backward(x, weight, y, rn, t, w_img)
         ctx.has_bias = bias is not None

@@ -145,8 +145,9 @@ class StemGradExchange:
         assert weight is self.weight
         self.captured = (z, gc, s2, c, scale)
 
-    def finish(self):
-        """all-gather the factors and write the full-batch gradient into weight.grad (call after backward)"""
+    def finish(self, run_collectives=None):
+        """all-gather the factors and write the full-batch gradient into weight.grad (call after backward).  `run_collectives(fn)`
+        executes the collectives (the step driver passes its communication-stream runner, PGGANTrainer._on_comm_stream)."""
         if self.captured is None:
             return
         z, gc, s2, c, scale = self.captured
@@ -154,8 +155,12 @@ class StemGradExchange:
         if self.world > 1:
             zs = torch.empty((self.world * b, k), device=z.device, dtype=z.dtype)
             gs = torch.empty((self.world * b,) + tuple(gc.shape[1:]), device=gc.device, dtype=gc.dtype)
-            dist.all_gather_into_tensor(zs, z.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(gs, gc.contiguous(), group=self.group)
+            zc, gcc = z.contiguous(), gc.contiguous()
+
+            def gather():
+                dist.all_gather_into_tensor(zs, zc, group=self.group)
+                dist.all_gather_into_tensor(gs, gcc, group=self.group)
+            (run_collectives or (lambda fn: fn()))(gather)
         else:
             zs, gs = z, gc
         self.wgrad_fn(zs, gs, self.weight.grad, zs.shape[0], k, s2, c, scale)
@@ -220,8 +225,13 @@ class PGGANTrainer:
             self.enable_stem_exchange()
         self.force_exchange = False
         self.last_z_g = None
-        self.refresh_stage()
+        # collectives of the RCCL backend run on a stream of their own (see _on_comm_stream); created on first need
+        self._comm_stream = None
+        if self.device.type == "cuda" and dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == "nccl":
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        self._graphs = {}          # input shape -> captured graphs of this stage (capture / replay)
         self._graph = None
+        self.refresh_stage()
         ops.bump_weight_epoch()
 
     def enable_stem_exchange(self):
@@ -236,6 +246,7 @@ class PGGANTrainer:
         """Call after any growth event (increase_resolution / a transition completing)."""
         self.flat_g.set_active(active_parameters(self.G))
         self.flat_d.set_active(active_parameters(self.D))
+        self._graphs = {}          # the captured graphs belong to the previous stage's module structure
         self._graph = None
 
     def start_epoch(self, epoch, transit_sch=()):
@@ -264,36 +275,52 @@ class PGGANTrainer:
             return sample_latent_vec_device((batch, self.G.latent_dim), self.device)
         return sample_latent_vec((batch, self.G.latent_dim), device=self.device)
 
+    def _on_comm_stream(self, fn):
+        """Run the collectives of `fn` on this trainer's communication stream, ordered after the work already queued on the current
+        stream and before whatever the current stream does next.
+
+        Why a stream of their own (the abort on record: gpurun_out/fd2.log of round 1, tools/capture_event_probe.py reproduces it):
+        a synchronous c10d collective records its completion event on the stream it was issued on, and the process group's
+        watchdog thread polls that event with hipEventQuery until a poll finds it complete (~100 ms period).  HIP refuses
+        hipEventQuery on an event whose last-recorded stream is part of an ACTIVE capture (hipErrorCapturedEvent) and the watchdog
+        turns that into std::terminate.  Streams of the training code do become part of captures: a captured backward pass forks
+        the stream on which a parameter's AccumulateGrad node was created into the capture.  So a collective issued on such a stream
+        shortly before capture() (warm-up iterations, the exchanges between captured segments, the last replayed step before a growth
+        event's re-capture) killed the process whenever the watchdog had not polled it yet.  Nothing but collectives ever runs on the
+        communication stream -- no autograd node is created on it, no capture is begun on it, no captured stream waits on it -- so it
+        can never be part of a capture and the watchdog may poll its events at any time.  (CPU tensors / the gloo rehearsal have no
+        such event and run in line.)"""
+        if self._comm_stream is None:
+            return fn()
+        cur = torch.cuda.current_stream()
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            fn()
+        cur.wait_stream(self._comm_stream)
+
     def _exchange(self, flat):
         if flat is self.flat_g and self.stem is not None:
             # the stem occupies the head of G's flat buffer: gather its factors, all-reduce only the tail
-            self.stem.finish()
+            self.stem.finish(self._on_comm_stream)
             if self.world > 1 or self.force_exchange:
-                dist.all_reduce(flat.grad[self._stem_elems:], op=dist.ReduceOp.SUM, group=self.group)
+                self._on_comm_stream(lambda: dist.all_reduce(flat.grad[self._stem_elems:], op=dist.ReduceOp.SUM, group=self.group))
             return
-        exchange_gradients(flat, self.world, self.group, force=self.force_exchange)
-
-    def _exchange_between_captures(self, flat):
-        """The exchange issued between two graph captures, fenced by host synchronisation on both sides: the previous segment's
-        capture is completely closed before the collective is enqueued and the collective is complete before the next capture
-        begins (replayed steps use the plain stream-ordered `_exchange`).  Together with the "thread_local" capture mode this keeps
-        the process group's watchdog thread (which polls collective events with hipEventQuery) out of the capture's way; an abort
-        with hipErrorCapturedEvent was seen once in ~15 runs of the unfenced version.  (Running this collective on a dedicated
-        stream instead was tried: replay then slowed down 20x in the two-rank gloo rehearsal.)"""
-        torch.cuda.synchronize()
-        self._exchange(flat)
-        torch.cuda.synchronize()
+        if self.world > 1 or self.force_exchange:
+            self._on_comm_stream(lambda: exchange_gradients(flat, self.world, self.group, force=self.force_exchange))
 
     def d_compute(self, real, z_d=None, z_gp=None, eps=None):
         """D half-step up to (and including) the backward pass: gradients end up in flat_d.grad."""
         b = real.size(0)
         self.flat_d.ensure_grad_views()
         self.flat_d.zero_grad()  # Discriminator_net.zero_grad(), train.py:357
-        # the two detached generator passes of the D step (loss_functions.py:26, 167) run as one batch-2b pass
+        # the two detached generator passes of the D step (loss_functions.py:26, 167) run as one batch-2b pass; with the penalty
+        # switched off (Lambda = 0, the reference CLI's default) the reference draws no second latent batch, and neither does this
+        with_gp = self.gp_loss.Lambda > 0
         with torch.no_grad():
-            fakes = self.G(torch.cat([self._latent(b, z_d), self._latent(b, z_gp)], dim=0))
+            zs = [self._latent(b, z_d)] + ([self._latent(b, z_gp)] if with_gp else [])
+            fakes = self.G(torch.cat(zs, dim=0) if with_gp else zs[0])
         loss, s_real, s_fake = self.d_loss(real, fake_images=fakes[:b])  # train.py:358
-        gp = self.gp_loss(real, x_tilde=fakes[b:], epsilon=eps)  # train.py:361
+        gp = self.gp_loss(real, x_tilde=fakes[b:] if with_gp else None, epsilon=eps)  # train.py:361
         loss = loss + gp  # train.py:362
         with ops.deferred_wgrad():   # weight-gradient slabs of the whole pass are reduced by one launch at the end
             loss.backward()  # train.py:365
@@ -366,73 +393,118 @@ class PGGANTrainer:
             opt.set_lr(st["lr"])
 
     # ---- HIP-graph capture of a whole iteration ---------------------------------------------------------------
-    def capture(self, real_example, warmup=3):
+    def _training_state(self):
+        """everything a training iteration changes on the device (parameters, Adam moments and step counts, the device RNG)"""
+        bufs = []
+        for flat in (self.flat_g, self.flat_d):
+            bufs += [flat.flat, flat.exp_avg, flat.exp_avg_sq, flat.seg_step]
+        return bufs
+
+    def capture(self, real_example, warmup=1, draws=None):
         """Capture `train_iteration` for this batch shape into HIP graphs (latents and epsilon drawn on the GPU inside
-        the graph).  Afterwards `replay(real)` copies `real` into the static input and launches them.
-        One GPU: one graph for the whole iteration.  Data parallel: three graphs -- [D forward/backward],
-        [D Adam, G forward/backward], [G Adam] -- with the two gradient all-reduces issued eagerly between them, so no
-        collective is ever captured."""
-        if not self.device_latents:
-            raise RuntimeError("graph capture needs device_latents=True (CPU-drawn latents cannot be replayed)")
+        the graph).  Afterwards `replay(real)` copies `real` into the static input of the graphs captured for its shape and
+        launches them.  One GPU: one graph for the whole iteration.  Data parallel: three graphs -- [D forward/backward],
+        [D Adam, G forward/backward], [G Adam] -- with the two gradient exchanges issued eagerly between them (on the
+        communication stream, `_on_comm_stream`), so no collective is ever captured.
+
+        capture() trains nothing: the warm-up iterations (they register and allocate the packed weight copies, workspaces and the
+        allocator's blocks outside the capture) run on a snapshot -- parameters, Adam moments, per-tensor step counts and the device
+        RNG state are restored afterwards -- and a stream capture itself executes no kernel.  The reference makes exactly one update
+        per batch (train.py:350-385); so does capture() + replay().  Graphs are kept per input shape until the next growth event
+        (`refresh_stage`), so a ragged last batch costs one extra capture per stage, not two per epoch.
+
+        draws: optional dict of STATIC device tensors {"z_d", "z_gp", "eps", "z_g"} used instead of drawing inside the graph; the
+        caller refills them before each replay (how the parity tests replay an eager trajectory exactly)."""
+        if draws is None and not self.device_latents:
+            raise RuntimeError("graph capture needs device_latents=True or static draws (CPU-drawn latents cannot be replayed)")
+        dr = draws or {}
+        d_args = (dr.get("z_d"), dr.get("z_gp"), dr.get("eps"))
+        z_g = dr.get("z_g")
         segmented = self.world > 1 or self.force_exchange
         if segmented and self.n_critic != 1:
             raise RuntimeError("segmented (data-parallel) capture supports n_critic = 1")
-        self._static_real = real_example.clone()
+        static_real = real_example.clone()
+        state = self._training_state()
+        saved = [t.clone() for t in state]
+        rng = torch.cuda.get_rng_state(self.device)
+        lr_g, lr_d = self.opt_g.param_groups[0]["lr"], self.opt_d.param_groups[0]["lr"]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.train_iteration(self._static_real)
+            for _ in range(max(1, warmup)):
+                self.train_iteration(static_real, *d_args, z_g)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        for t, v in zip(state, saved):
+            t.copy_(v)
+        del saved
+        torch.cuda.set_rng_state(rng, self.device)
+        assert (lr_g, lr_d) == (self.opt_g.param_groups[0]["lr"], self.opt_d.param_groups[0]["lr"])
         ops.bump_weight_epoch()   # the warm-up registered every packed weight (persistent buffers, allocated outside capture):
-        self.opt_d.repack()       # rebuild both re-pack tables now, so that the captured Adam steps find them complete
-        self.opt_g.repack()
+        self.opt_d.repack()       # rebuild both re-pack tables now (from the restored parameters), so that the captured Adam
+        self.opt_g.repack()       # steps find them complete
         ops.refresh_packed()      # (copies of tensors that belong to neither optimiser)
-        # With a process group alive, its watchdog thread polls the events of earlier collectives (hipEventQuery) while a segment
-        # is being captured; in the default "global" capture mode HIP turns that into an error that kills the process
-        # (intermittently: it depends on whether the watchdog had already reaped the previous collective).  "thread_local" only
-        # polices the capturing thread.
-        mode = os.environ.get("NGAN_CAPTURE_MODE") or ("thread_local" if (dist.is_available() and dist.is_initialized()) else "global")
-        if segmented:
-            torch.cuda.synchronize()
-            if self.world > 1 or self.force_exchange:
-                dist.barrier(group=self.group)          # every rank's warm-up collectives are complete before the first capture
-                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        mode = os.environ.get("NGAN_CAPTURE_MODE", "global")
         if not segmented:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode=mode):
-                self._static_stats = self.train_iteration(self._static_real)
-            self._graph = [graph]
+                stats = self.train_iteration(static_real, *d_args, z_g)
+            graphs = [graph]
         else:
             ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, capture_error_mode=mode):
-                stats = self.d_compute(self._static_real)
-            self._exchange_between_captures(self.flat_d)
+                stats = self.d_compute(static_real, *d_args)
+            self._exchange(self.flat_d)                  # eager, on the communication stream; its result is discarded below
             with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=mode):
                 self.opt_d.step()
-                stats.update(self.g_compute(self._static_real))
-            self._exchange_between_captures(self.flat_g)
+                stats.update(self.g_compute(static_real, z_g))
+            self._exchange(self.flat_g)
             with torch.cuda.graph(gc, pool=ga.pool(), capture_error_mode=mode):
                 self.opt_g.step()
-            self._static_stats = stats
-            self._graph = [ga, gb, gc]
-        return self._graph
+            graphs = [ga, gb, gc]
+            torch.cuda.synchronize()
+            self.flat_d.grad.zero_()                     # the exchanges above summed never-computed gradients: leave nothing behind
+            self.flat_g.grad.zero_()
+        self._graph = graphs
+        self._static_real, self._static_stats = static_real, stats
+        self._graphs[tuple(real_example.shape)] = (graphs, static_real, stats)
+        return graphs
+
+    def has_graph(self, shape):
+        return tuple(shape) in self._graphs
 
     def replay(self, real=None):
-        if self._graph is None:
-            raise RuntimeError("call capture() first (and again after every growth event)")
+        """One training iteration from the captured graphs.  `real` selects the graphs by its shape (capture() them first);
+        without an argument the most recently captured graphs run on their static input as it stands."""
         if real is not None:
-            self._static_real.copy_(real, non_blocking=True)
-        if len(self._graph) == 1:
-            self._graph[0].replay()
+            entry = self._graphs.get(tuple(real.shape))
+            if entry is None:
+                raise RuntimeError(f"no graphs captured for input shape {tuple(real.shape)}: call capture() first (and again after "
+                                   f"every growth event)")
+            graphs, static_real, stats = entry
+            static_real.copy_(real, non_blocking=True)
         else:
-            self._graph[0].replay()
+            if self._graph is None:
+                raise RuntimeError("call capture() first (and again after every growth event)")
+            graphs, stats = self._graph, self._static_stats
+        if len(graphs) == 1:
+            graphs[0].replay()
+        else:
+            graphs[0].replay()
             self._exchange(self.flat_d)
-            self._graph[1].replay()
+            graphs[1].replay()
             self._exchange(self.flat_g)
-            self._graph[2].replay()
-        return self._static_stats
+            graphs[2].replay()
+        return stats
+
+    def step(self, real, use_graph=True):
+        """train on one batch: graph replay when possible (capturing on first sight of a shape), else eager"""
+        if use_graph and self.device_latents and self.n_critic == 1:
+            if not self.has_graph(real.shape):
+                self.capture(real)
+            return self.replay(real)
+        return self.train_iteration(real)
 
 
 # =====================================================================================================================
@@ -496,7 +568,6 @@ def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_fina
     pending = [None, None]
     series = {n: [] for n in names}
     dataset.set_image_size(G.image_size)
-    graph_shape = None
     start_time = time.time()
 
     def consume(slot):
@@ -524,7 +595,6 @@ def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_fina
     for epoch in range(epoch_init, epoch_final):
         if trainer.start_epoch(epoch, cfg.transit_sch):
             dataset.set_image_size(G.image_size)
-            graph_shape = None
         # number of critic steps this epoch (train.py:336-340); the score series lags one epoch here (deferred read-back)
         if adapt_critic and len(series["score_real"]) > adapt_period:
             n_d_steps = Calculate_D_steps(series["score_real"], series["score_fake"], 0, cfg.n_critic, Period=adapt_period)
@@ -540,14 +610,8 @@ def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_fina
             else:
                 images = torch.stack([dataset[j] for j in order[i:i + cfg.batch_size]]).to(dev)
             b = images.size(0)
-            if use_graph and trainer.device_latents and n_d_steps == 1:
-                if graph_shape != tuple(images.shape):
-                    trainer.capture(images, warmup=1)                # (re)capture after growth or a ragged last batch
-                    graph_shape = tuple(images.shape)
-                stats = trainer.replay(images)
-            else:
-                trainer.n_critic = n_d_steps
-                stats = trainer.train_iteration(images)
+            trainer.n_critic = n_d_steps
+            stats = trainer.step(images, use_graph=use_graph)        # graphs are cached per shape until the next growth event
             g_loss = stats["G_loss"]
             if sim_lambda > 0:
                 # the reference adds similarity_loss(real images, latents) to the generator loss (train.py:379-381); it depends on
@@ -644,24 +708,33 @@ def main(argv=None):
     n_up = len(config.N_gen_features) - 1
     if options.images:
         data = torch.load(options.images) if options.images.endswith('.pt') else torch.from_numpy(np.load(options.images))
-        dataset = TensorImageDataset(data.float().to(device))
+        data = data.float()
+        if data.dim() == 4 and data.shape[1] == 1:
+            # single-colour images: the device dataset with the reference's augmentation chain (data/NeuronDataset.py:112-126,
+            # antialiased Resize to the stage resolution); it takes [0, 1] images and renormalises to [-1, 1] itself
+            from .data import NeuronDataset
+            dataset = NeuronDataset((data + 1.0) * 0.5, augmentations=True, im_translation=float(getattr(config, 'translation', 0.0)),
+                                    device=device, seed=config.seed)
+        else:
+            dataset = TensorImageDataset(data.to(device))
     else:
         dataset = TensorImageDataset.synthetic(16, config.image_size, config.N_colors, device=device)
     size_init = dataset.image_size_max // (2 ** n_up)                                       # train.py:162-165
     G = models.Generator_PG(config.N_gen_features, image_size_init=size_init).to(device)    # train.py:172-175
     D = models.Discriminator_PG(config.N_dis_features, image_size_init=size_init).to(device)
     filename = os.path.join(config.weights_dir, 'GenDisc_{}.pth'.format(config.ID))         # train.py:196-197
-    trainer = None
-    checkpoint = Checkpointer(G, D, config.learning_rate, filename, N_epochs=config.N_epochs, device=device, extra_checkpoint_period=1e3)
+    # the trainer exists before the checkpoint is read, so that `--resume` also restores the optimiser state this implementation
+    # adds to its checkpoints (Adam moments and per-tensor step counts; the reference saves none, utils.py:160-169)
+    trainer = PGGANTrainer(G, D, learning_rate=config.learning_rate, beta1=config.beta1, grad_pen_lambda=config.grad_pen_lambda,
+                           drift_epsilon=config.drift_epsilon, n_critic=config.n_critic, alpha_step=config.alpha_step,
+                           device_latents=True)
+    checkpoint = Checkpointer(G, D, config.learning_rate, filename, N_epochs=config.N_epochs, device=device, extra_checkpoint_period=1e3,
+                              trainer=trainer)
     if config.resume and os.path.exists(filename):
         checkpoint.load_state()
     elif config.weights_init:
         checkpoint.load_state(os.path.join(config.weights_dir, config.weights_init))
     assert G.image_size == D.image_size, 'The generator and discriminator are at different resolution'   # train.py:215-216
-    trainer = PGGANTrainer(G, D, learning_rate=config.learning_rate, beta1=config.beta1, grad_pen_lambda=config.grad_pen_lambda,
-                           drift_epsilon=config.drift_epsilon, n_critic=config.n_critic, alpha_step=config.alpha_step,
-                           device_latents=True)
-    checkpoint.trainer = trainer
     epoch_init = checkpoint.epoch + 1
     lr0 = lr_schedule(epoch_init - 1, config.learning_rate, config.transit_sch, config.N_epochs)       # train.py:288-289
     if lr0 is not None:

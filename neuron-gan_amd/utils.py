@@ -64,10 +64,21 @@ def set_saved_attrs(model, saved_attrs_dict):
     return saved_attrs_dict
 
 
+def _numpy_allow_list():
+    """What a reference checkpoint needs beyond tensors and plain containers: numpy arrays of plain numeric dtypes (the four loss
+    series, utils.py:160-169).  Array reconstruction from a raw buffer executes nothing from the file."""
+    core = getattr(np, "_core", None) or np.core
+    return [np.ndarray, np.dtype, core.multiarray._reconstruct] + \
+           [type(np.dtype(t)) for t in (np.float64, np.float32, np.float16, np.int64, np.int32, np.int16, np.int8, np.uint8, np.bool_)]
+
+
 def load_checkpoint_dict(filename, device=torch.device('cpu')):
-    """The reference's checkpoints hold numpy arrays (loss series), which torch's weights-only unpickler refuses; they are
-    the user's own training artefacts, so the full unpickler is used (as the reference does, utils.py:185, models.py:397)."""
-    return torch.load(filename, map_location=device, weights_only=False)
+    """torch.load with the weights-only unpickler: checkpoint files come from users and from the reference's download link
+    (gen_dis_default.pth, setup.py:79), so nothing in them may execute.  The reference's own `torch.load` (utils.py:185,
+    models.py:397) is the full unpickler; the only non-tensor payload its checkpoints hold are numpy loss series, which are
+    allow-listed explicitly.  A file that needs anything else is refused with torch's error."""
+    with torch.serialization.safe_globals(_numpy_allow_list()):
+        return torch.load(filename, map_location=device, weights_only=True)
 
 
 class Checkpointer:

@@ -28,7 +28,7 @@ def test_from_state_dict_matches_reference_loader(ngan, tag):
 
 
 def test_checkpointer_writes_the_reference_layout(ngan, tmp_path):
-    ref = torch.load(os.path.join(GOLDEN, "ref_checkpoint_new.pth"), weights_only=False)   # our own fixture file
+    ref = ngan.utils.load_checkpoint_dict(os.path.join(GOLDEN, "ref_checkpoint_new.pth"))
     G = ngan.models.Generator_PG([16, 16, 16], image_size_init=4)
     D = ngan.models.Discriminator_PG([16, 16, 16], image_size_init=4)
     G.set_resolution(8, 1.0)
@@ -37,7 +37,7 @@ def test_checkpointer_writes_the_reference_layout(ngan, tmp_path):
     ck = ngan.utils.Checkpointer(G, D, 1e-4, f, N_epochs=20, verbose=False, extra_checkpoint_period=1e3)
     ck.Loss_real[:5] = np.arange(5.0)
     ck.save_state(5)
-    mine = torch.load(f, weights_only=False)
+    mine = ngan.utils.load_checkpoint_dict(f)
     assert set(ref.keys()) <= set(mine.keys())                      # same keys (an optimizer_state key may be added)
     assert set(mine["Generator_attrs"]) == set(ref["Generator_attrs"]) and set(mine["Discriminator_attrs"]) == set(ref["Discriminator_attrs"])
     assert list(mine["Generator_state"].keys()) == list(ref["Generator_state"].keys())
@@ -58,6 +58,25 @@ def test_checkpointer_writes_the_reference_layout(ngan, tmp_path):
     ck3.load_state(os.path.join(GOLDEN, "ref_checkpoint_new.pth"))
     assert ck3.epoch == 0 and G3.image_size == 8
     assert torch.equal(G3.state_dict()["layers.0.weight"], ref["Generator_state"]["layers.0.weight"])
+
+
+def test_checkpoint_loader_executes_nothing_from_the_file(ngan, tmp_path):
+    """Checkpoints are loaded with torch's weights-only unpickler plus an explicit numpy allow-list (the reference's files hold
+    numpy loss series).  A pickle that wants to call anything else is refused, not run."""
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("touch " + str(tmp_path / "pwned"),))
+    f = str(tmp_path / "evil.pth")
+    torch.save({"epoch": 1, "payload": Evil()}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        ngan.utils.load_checkpoint_dict(f)
+    assert not os.path.exists(str(tmp_path / "pwned"))
+    G = ngan.models.Generator_PG([16, 16, 16], image_size_init=4)
+    with pytest.raises(pickle.UnpicklingError):
+        type(G).from_state_dict(f, verbose=False)
+    assert not os.path.exists(str(tmp_path / "pwned"))
 
 
 def test_image_grid_and_cli_parser(ngan):

@@ -98,3 +98,32 @@ def _worker(rank, world, port, fixture):
 @pytest.mark.parametrize("fixture", ["small_res8_warm", "small_res16_fade_warm"])
 def test_two_rank_gradient_exchange_equals_big_batch(fixture):
     mp.spawn(_worker, args=(2, _free_port(), fixture), nprocs=2, join=True)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` is the driver's multi-GPU command: with no launcher environment the script itself must start
+    the N rank processes (before anything touches a GPU) and rank 0 must print one JSON line whose n_gpus is N and whose observed
+    world size -- read back from the process group the ranks formed -- is N too.  `--launch-check` runs that path on the CPU (gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_observed"] == 2 and out["sum_of_ones"] == 2.0
+    # a rank count that disagrees with the launcher's world size is refused, not silently accepted
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"],
+                         env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_bench_parent_never_imports_torch():
+    """The launcher process must not initialise HIP: it does not even import torch (checked on the source: everything above
+    `launch_ranks` is stdlib, torch is imported inside the rank-side functions only)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def main()")]
+    top_level_imports = [ln for ln in head.splitlines() if ln.startswith("import ") or ln.startswith("from ")]
+    assert not any("torch" in ln or "__graft_entry__" in ln for ln in top_level_imports), top_level_imports

@@ -88,3 +88,87 @@ def test_two_ranks_on_one_gpu_match_the_whole_batch(fixture):
     results = sorted(q.get(timeout=5) for _ in range(2))
     assert results == [(0, "ok"), (1, "ok")], results
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _capture_worker(port, fixture, q):
+    """One rank, a real RCCL process group (watchdog thread alive), force_exchange: the three-segment capture, two replays and a
+    re-capture must (a) train nothing while capturing, (b) reproduce the eager `train_iteration` trajectory bit for bit on the same
+    reals / latents / epsilon, (c) never trip the watchdog's event poll (the round-1 abort, tools/capture_event_probe.py)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from __graft_entry__ import load_package
+        from conftest import load_golden
+        import test_gpu_models as T
+        ngan = load_package()
+        fix = load_golden(fixture)
+        batch, latent = int(fix["meta"][4]), int(fix["meta"][3])
+        res = int(fix["meta"][0])
+
+        def make():
+            G, D = T.build_small(ngan, fix)
+            tr = ngan.train.PGGANTrainer(G, D, learning_rate=1e-3)
+            tr.force_exchange = True
+            tr.enable_stem_exchange()
+            assert tr.stem is not None and tr._comm_stream is not None
+            return tr
+
+        gen = torch.Generator().manual_seed(77)
+        steps = []
+        for _ in range(3):
+            z = [torch.randn(batch, latent, generator=gen) for _ in range(3)]
+            z = [(v / v.norm(dim=1, keepdim=True)).to(dev) for v in z]
+            steps.append(dict(real=(torch.rand(batch, 1, res, res, generator=gen) * 2 - 1).to(dev), z_d=z[0], z_gp=z[1],
+                              eps=torch.rand(batch, 1, 1, 1, generator=gen).to(dev), z_g=z[2]))
+        eager = make()
+        for s in steps[:2]:
+            eager.train_iteration(s["real"], s["z_d"], s["z_gp"], s["eps"], s["z_g"])
+        tr = make()
+        static = {k: steps[0][k].clone() for k in ("z_d", "z_gp", "eps", "z_g")}
+        before = [t.clone() for t in tr._training_state()]
+        tr.capture(steps[0]["real"], warmup=2, draws=static)
+        assert len(tr._graph) == 3                                      # segmented: [D fwd/bwd] x [D Adam, G fwd/bwd] x [G Adam]
+        for a, b in zip(before, tr._training_state()):
+            assert torch.equal(a, b), "capture() must not train"
+        for s in steps[:2]:
+            for k, v in static.items():
+                v.copy_(s[k])
+            tr.replay(s["real"])
+        torch.cuda.synchronize()
+        for name, p, pe in zip(tr.flat_g.names + tr.flat_d.names, tr.flat_g.params + tr.flat_d.params, eager.flat_g.params + eager.flat_d.params):
+            assert torch.equal(p, pe), f"{name}: replayed and eager trajectories differ by {float((p - pe).abs().max())}"
+        for flat in (tr.flat_g, tr.flat_d):
+            st = flat.seg_step.cpu()
+            assert all(int(v) == (2 if a else 0) for v, a in zip(st, flat.active_host)), st   # one Adam step per batch, none from capturing
+        # a growth event's re-capture directly behind replayed steps (their collectives may not have been polled by the watchdog yet)
+        tr.refresh_stage()
+        tr.capture(steps[2]["real"], draws=static)
+        eager.train_iteration(steps[2]["real"], *(steps[2][k] for k in ("z_d", "z_gp", "eps", "z_g")))
+        for k, v in static.items():
+            v.copy_(steps[2][k])
+        tr.replay(steps[2]["real"])
+        torch.cuda.synchronize()
+        import time
+        time.sleep(0.5)                                                   # several watchdog polls
+        assert all(torch.equal(p, pe) for p, pe in zip(tr.flat_d.params, eager.flat_d.params))
+        q.put("ok")
+    except Exception as e:  # noqa: BLE001
+        q.put(repr(e))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_segmented_capture_with_a_live_rccl_group_matches_eager():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_capture_worker, args=(_free_port(), "small_res16_fade_warm", q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0, f"worker exit code {p.exitcode} (an abort here is the watchdog / capture interaction)"
+    assert q.get(timeout=5) == "ok"

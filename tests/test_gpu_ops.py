@@ -196,8 +196,9 @@ def test_pixelnorm_handoff_matches_unfused(ngan, case, conv_precision):
 
 
 def test_folded_bilinear_border_modes(ngan):
-    """precision 3 through the C ABI: by default ngan_conv3x3_fwd writes the border ring itself; in split mode (what the Python
-    layer uses) the ring is left to ngan_conv3x3_up2_border.  Both must give the same tensor as the operator."""
+    """precision 3 through the C ABI: by default ngan_conv3x3_fwd writes the border ring itself; with the per-call flag
+    NGAN_CONV_SKIP_BORDER (what the Python layer passes) the ring is left to ngan_conv3x3_up2_border.  Both must give the same
+    tensor as the operator, and the flag of one call must not leak into the next (no global state in the library)."""
     ops, C = ngan.ops, ngan._C
     ops.set_conv_precision("bf16x3")
     try:
@@ -212,17 +213,16 @@ def test_folded_bilinear_border_modes(ngan):
         packed = ops._packed(w, 0, 0.1, prec)
         y = torch.full_like(y_ref, float("nan"))
         rn = torch.full_like(rn_ref, float("nan"))
-        assert C.lib().ngan_conv3x3_split_border(0) == 1        # the Python layer runs in split mode
-        try:
-            C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, B, H, W, K, N, 2, 1, 0, SLOPE, 1e-8, prec)
-        finally:
-            C.lib().ngan_conv3x3_split_border(1)
-        assert torch.equal(y, y_ref) and torch.equal(rn, rn_ref)
-        y.fill_(float("nan"))
-        C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, B, H, W, K, N, 2, 1, 0, SLOPE, 1e-8, prec)     # split: ring untouched
+        C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, B, H, W, K, N, 2, 1, 0, SLOPE, 1e-8, prec, C.CONV_SKIP_BORDER)   # ring untouched
         assert torch.isnan(y[:, 0]).all() and torch.isnan(y[:, :, 0]).all() and not torch.isnan(y[:, 1:-1, 1:-1]).any()
         C.call("ngan_conv3x3_up2_border", x, packed, bias, y, rn, B, H, W, K, N, 1, SLOPE, 1e-8)
-        assert torch.equal(y, y_ref)
+        assert torch.equal(y, y_ref) and torch.equal(rn, rn_ref)
+        y.fill_(float("nan"))
+        rn.fill_(float("nan"))
+        C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, B, H, W, K, N, 2, 1, 0, SLOPE, 1e-8, prec, 0)   # default: whole tensor, right after a flagged call
+        assert torch.equal(y, y_ref) and torch.equal(rn, rn_ref)
+        with pytest.raises(RuntimeError, match="unknown flags"):
+            C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, B, H, W, K, N, 2, 1, 0, SLOPE, 1e-8, prec, 6)
     finally:
         ops.set_conv_precision("f32")
 

@@ -86,7 +86,7 @@ def test_epoch_driver_grows_checkpoints_and_resumes(ngan, tmp_path):
     assert G.image_size == 16 and D.image_size == 16 and G.alpha_value() >= 1 and D.alpha_value() >= 1
     assert [k for k in G.state_dict() if k.startswith("conv_block_list")] == [] and len(G.layers) == 9
     assert os.path.exists(f) and os.path.exists(str(tmp_path / "Samples_t001_8.png"))
-    saved = torch.load(f, weights_only=False)
+    saved = ngan.utils.load_checkpoint_dict(f)
     assert saved["epoch"] == 8 and "optimizer_state" in saved and len(saved["Loss_real"]) == 8
     # the blocks that joined late have fewer Adam steps than the stem (torch skips .grad=None tensors)
     steps = dict(zip(saved["optimizer_state"]["D"]["names"], saved["optimizer_state"]["D"]["step"].tolist()))
@@ -108,6 +108,54 @@ def test_epoch_driver_grows_checkpoints_and_resumes(ngan, tmp_path):
     assert len(more["G_loss"]) == 1 and np.isfinite(more["G_loss"][0])
     grid = utils.plot_gen_samples(G2, N_images=4, seed=0)
     assert grid.shape[0] == 1 and grid.shape[1] > 2 * 16
+
+
+def test_one_update_per_batch_with_a_ragged_last_batch(ngan):
+    """10 images in batches of 4 -> batches of 4, 4, 2 per epoch.  The reference makes one optimiser step per batch
+    (train.py:350-385).  The graph path must too: capture() trains nothing (its warm-up runs on a snapshot), graphs are kept per
+    input shape, so three epochs cost two captures and exactly nine Adam steps."""
+    models, train = ngan.models, ngan.train
+    cfg = types.SimpleNamespace(adapt_critic=False, sim_loss_lambda=0.0, n_critic=1, batch_size=4, transit_sch=[], N_epochs=3,
+                                alpha_step=0.5, learning_rate=1e-3, checkpointing_period=100, ID="t002")
+    torch.manual_seed(6)
+    G = models.Generator_PG([32, 16], image_size_init=8, latent_dim=32).to(DEV)
+    D = models.Discriminator_PG([16, 32], image_size_init=8).to(DEV)
+    data = train.TensorImageDataset.synthetic(10, 8, device=DEV)
+    tr = train.PGGANTrainer(G, D, learning_rate=cfg.learning_rate, device_latents=True)
+    captures = []
+    real_capture = tr.capture
+    tr.capture = lambda x, *a, **k: (captures.append(tuple(x.shape)), real_capture(x, *a, **k))[1]
+    w0 = tr.flat_d.flat.clone()
+    real_capture(data.full[:4])
+    assert torch.equal(w0, tr.flat_d.flat) and float(tr.flat_d.seg_step.sum()) == 0.0        # capturing is not training
+    tr._graphs.clear()
+    series = train.pggan_train(tr, data, cfg, epoch_final=4, log=lambda *_: None)
+    assert len(series["G_loss"]) == 3 and np.isfinite(series["G_loss"]).all()
+    assert sorted(captures) == [(2, 1, 8, 8), (4, 1, 8, 8)], captures
+    for flat in (tr.flat_g, tr.flat_d):
+        steps = flat.seg_step.cpu().tolist()
+        assert all(s == (9.0 if a else 0.0) for s, a in zip(steps, flat.active_host)), steps
+    assert not torch.equal(w0, tr.flat_d.flat)
+
+
+def test_penalty_switched_off_draws_no_second_latent_batch(ngan):
+    """grad_pen_lambda = 0 is the reference CLI's argparse default: D_grad_pen_loss returns 0 (loss_functions.py:179) and draws
+    nothing.  The step driver must run (round 1 stacked a CPU scalar with device tensors) and must not generate the unused fakes."""
+    G = ngan.models.Generator_PG([32, 16], image_size_init=8, latent_dim=32).to(DEV)
+    D = ngan.models.Discriminator_PG([16, 32], image_size_init=8).to(DEV)
+    tr = ngan.train.PGGANTrainer(G, D, grad_pen_lambda=0.0, device_latents=True)
+    seen = []
+    inner = G.forward
+    G.forward = lambda z: (seen.append(z.shape[0]), inner(z))[1]
+    x = (torch.rand(4, 1, 8, 8) * 2 - 1).to(DEV)
+    stats = tr.train_iteration(x)
+    assert seen == [4, 4]                                   # one detached pass for the critic step, one pass in the generator step
+    assert float(stats["D_grad_pen"]) == 0.0 and stats["D_grad_pen"].device.type == "cuda"
+    cfg = types.SimpleNamespace(adapt_critic=False, sim_loss_lambda=0.0, n_critic=1, batch_size=4, transit_sch=[], N_epochs=1,
+                                alpha_step=0.5, learning_rate=1e-3, checkpointing_period=100, ID="t003")
+    G.forward = inner
+    series = ngan.train.pggan_train(tr, ngan.train.TensorImageDataset.synthetic(4, 8, device=DEV), cfg, epoch_final=2, log=lambda *_: None)
+    assert series["D_grad_pen"] == [0.0]
 
 
 def test_stem_factor_exchange_matches_plain_gradient(ngan):

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_invalid_arguments_return_status_not_crash(built):
     lib = built._C.lib()
     # null pointers / bad shapes are rejected on the host before any launch (no GPU needed)
-    assert lib.ngan_conv3x3_fwd(None, None, None, None, None, 1, 8, 8, 16, 16, 0, 0, 0, 0.2, 1e-8, 0, None) < 0
+    assert lib.ngan_conv3x3_fwd(None, None, None, None, None, 1, 8, 8, 16, 16, 0, 0, 0, 0.2, 1e-8, 0, 0, None) < 0
     assert b"null" in lib.ngan_last_error()
     assert built._C.wgrad_workspace_bytes(1, 8, 8, 16, 16) > 0
     assert built._C.wgrad_workspace_bytes(1, 8, 8, 12, 16) == 0

@@ -92,6 +92,24 @@ def test_flop_model_matches_survey():
         assert abs(got[0] / 1e9 - fg) < 2e-4 and abs(got[1] / 1e9 - fd) < 2e-4, (res, got)
 
 
+def test_package_work_model_matches_oracle_and_survey(ngan):
+    """neuron-gan_amd/workmodel.py (what bench.py divides by) against the oracle's independent count and SURVEY.md 8(d)'s
+    W_alg and E columns."""
+    wm = ngan.workmodel
+    g = [128, 64, 32, 32, 16, 16]
+    d = [16, 16, 32, 32, 64, 128]
+    want = {(16, 1.0): (1.604, 2.50), (64, 0.5): (7.046, 15.48), (256, 1.0): (23.084, 102.50), (512, 1.0): (43.739, 308.61)}
+    for (res, alpha), (w_alg, e) in want.items():
+        assert wm.forward_flops(g, d, 16, res, 512, alpha) == O.forward_flops(g, d, 16, res, 512, alpha)
+        assert abs(wm.iteration_flops(g, d, 16, res, 512, alpha) / 1e9 - w_alg) < 1e-3
+        assert abs(wm.iteration_io_elements(g, d, 16, res, 512, alpha) / 1e6 - e) < 1e-2
+    # other widths / colours / fade-in stages: the two counts are independent implementations
+    for res, alpha, nc in [(32, 0.3, 3), (128, 1.0, 1), (512, 0.5, 1)]:
+        a = wm.forward_flops([64, 32, 32, 16, 16, 16], [16, 32, 32, 32, 64, 64], 16, res, 128, alpha, nc)
+        b = O.forward_flops([64, 32, 32, 16, 16, 16], [16, 32, 32, 32, 64, 64], 16, res, 128, alpha, nc)
+        assert a == b, (res, alpha, a, b)
+
+
 def test_latent_sampler_pin():
     """seed 7 -> z[0,:3]."""
     torch.manual_seed(7)

@@ -36,7 +36,7 @@ if a.op == "fwd":
     y = torch.empty(a.B, oh, ow, a.N, device=dev)
     rn = torch.empty(a.B, a.H, a.W, device=dev)
     def run():
-        C.call("ngan_conv3x3_fwd", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.res, a.epi, a.out, 0.2, 1e-8, prec)
+        C.call("ngan_conv3x3_fwd", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.res, a.epi, a.out, 0.2, 1e-8, prec, C.CONV_SKIP_BORDER if prec == 3 else 0)
         if prec == 3:      # folded bilinear: the border ring is its own launch in the Python layer's split mode (include/ngan.h)
             C.call("ngan_conv3x3_up2_border", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.epi, 0.2, 1e-8)
 else:

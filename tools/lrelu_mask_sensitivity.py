@@ -17,7 +17,7 @@ for prec in (0, 1):
     packed = torch.empty(C.conv3x3_packed_floats(Cout, Cin, p), device="cuda")
     C.call("ngan_conv3x3_pack_weights", w, packed, Cout, Cin, 0, scale, p)
     y = torch.empty(B, H, W, Cout, device="cuda"); rn = torch.empty(B, H, W, device="cuda")
-    C.call("ngan_conv3x3_fwd", x, packed, None, y, rn, B, H, W, Cin, Cout, 0, 1, 0, 0.2, 1e-8, p)
+    C.call("ngan_conv3x3_fwd", x, packed, None, y, rn, B, H, W, Cin, Cout, 0, 1, 0, 0.2, 1e-8, p, 0)
     gc = torch.empty_like(y)
     C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, B * H * W, Cout, 0.2)
     torch.cuda.synchronize()

@@ -8,7 +8,7 @@ dev = "cuda:0"
 def run(B,H,W,K,N):
     x = torch.randn(B,H,W,K, device=dev); w = torch.randn(N,K,3,3, device=dev)
     packed = ops._packed(w, 0, 0.1, 1); y = torch.empty(B,H,W,N, device=dev)
-    f = lambda: C.call("ngan_conv3x3_fwd", x, packed, None, y, None, B,H,W,K,N,0,0,0,0.2,1e-8,1)
+    f = lambda: C.call("ngan_conv3x3_fwd", x, packed, None, y, None, B,H,W,K,N,0,0,0,0.2,1e-8,1,0)
     for _ in range(3): f()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
