@@ -10,6 +10,7 @@
 // channels with two shuffles and stores 16 B per lane, fully coalesced.
 // The avg-pool / bilinear-x2 resampling in front of a block's first conv (models.py:254, 257) is applied
 // while the halo tile is staged, so the resampled tensor never exists in HBM.
+#include <cstdlib>
 #include "conv3x3_shared.h"
 
 namespace {
@@ -304,6 +305,33 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 // tile t+1 before the MFMAs of tile t, so every CU always has a tile's worth of loads in flight.
 // Bilinear x2 input: the low-resolution source patch (6x18 pixels) is staged once and expanded LDS -> LDS.
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// Tile schedule of the persistent kernels: as many workgroups as are resident, an equal share of tiles each, strided inside the
+// band of the workgroup's XCD (blockIdx & 7), so that neighbouring tiles meet in one L2 at about the same time.
+// Measured and rejected (tools/clock_probe.py, fp32 16 -> 16 at 512x512, 177 us): the workgroups of a CU finish up to 75 us apart
+// (the waves sharing a SIMD are served oldest first), but neither an atomic ticket queue (220 us: the compiler guards the tile
+// loop's register hazards with s_waitcnt vmcnt(0..1), so every tile waited for the in-flight atomic) nor an over-decomposed grid
+// that the dispatcher back-fills (2 / 4 / 8 tiles per workgroup: 184 / 181 / 180 us) is faster: the tail is not where the time goes.
+// What the fp32 instances are short of is VALU issue: v_mfma_f32_16x16x4_f32 runs at the vector-FMA rate and does not overlap
+// with other waves' VALU work -- with loads, stores, LDS staging and the epilogue compiled out one by one the kernel loses exactly
+// the issue time of the instructions removed (161 / 143 / 132 us; the MFMAs alone need 123).
+// ---------------------------------------------------------------------------------------------------------
+struct TileRun { int t, t_end, step; };
+__device__ __forceinline__ TileRun tile_run(int n_tiles) {      // this workgroup's tiles: t, t + step, ... < t_end
+    const int xcd = blockIdx.x & 7, band = (n_tiles + 7) >> 3;
+    TileRun r;
+    r.step = gridDim.x >> 3;
+    r.t = xcd * band + (blockIdx.x >> 3);
+    r.t_end = min((xcd + 1) * band, n_tiles);
+    return r;
+}
+
+inline int persistent_grid(int n_tiles, int resident) {
+    int grid = resident < n_tiles ? resident : n_tiles;
+    grid &= ~7;
+    return grid < 8 ? 8 : grid;
+}
+
 // "The value must be in its registers HERE": an empty asm that reads and writes v (conv3x3_up2f_kernel).  (a) On the prefetched tile
 // registers right after the MFMAs, before the epilogue's stores are issued: gfx9 counts loads and stores in ONE counter (vmcnt) and
 // they may retire out of order with each other, so once stores are in flight the compiler can only wait for a load with vmcnt(0),
@@ -346,8 +374,18 @@ __device__ __forceinline__ void st_split(float* tile, int idx, float4 v) {
 // (the bilinear 32-channel instances also use 4 rows: with 8 their tile + low-res patch + weights come to 83 KB, one workgroup per CU)
 constexpr int persist_tile_h(int MTW, int KG, int RES) { return (MTW * KG == 4 || (KG == 2 && RES == NGAN_RESAMPLE_UP2)) ? 4 : 8; }
 
+#ifdef NGAN_CLOCK_PROBE
+// Diagnostic build only (tools/clock_probe.py, `make clockprobe`): every workgroup of the persistent kernel stamps the shader clock
+// (s_memtime) and the 100 MHz reference clock (s_memrealtime) on entry and exit; in-kernel clock = d(memtime) / d(realtime) x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to a buffer nothing else reads.
+__device__ unsigned long long g_clock_stamps[4 * 8192];
+#endif
+
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
+#ifdef NGAN_CLOCK_PROBE
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // tile: 8 x 32 pixels, 4 pixel groups of 16 per wave; the 32 -> 32 instances use 4 x 32 (2 groups per wave): their 8-row tile
     // needs 88 KB of LDS and ~260 registers, i.e. ONE workgroup per CU with nothing to overlap its load / barrier / MFMA phases
     constexpr int THc = persist_tile_h(MTW, KG, RES), PGW = THc / 2, RPW = THc / 4;
@@ -369,26 +407,29 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
 
     for (int e = tid; e < W_ELEMS / 4; e += 256) st4(wl + e * 4, ld4(a.wp + e * 4));
 
-    const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
-    const int band = (n_tiles + 7) >> 3;
-    const int t_end = min((xcd + 1) * band, n_tiles);
-    int t = xcd * band + (blockIdx.x >> 3);
+    const TileRun run = tile_run(n_tiles);
+    int t = run.t;
+    const int t_end = run.t_end;
     const int h = a.H >> 1, w = a.W >> 1;
 
     // ---- tile-invariant per-thread staging descriptors (all index arithmetic happens once, here) ----
-    int s_dy[NST], s_dx[NST], s_ch[NST], s_lds[NST];   // source pixel offset from the tile origin, channel, LDS float index
+    // source pixel offset from the tile origin (dy in the high half, dx in the low half of one register: the kernel runs at its
+    // register cap, and the ticket of the dynamic tile schedule must stay in a register for a whole tile), channel, LDS float index
+    int s_dyx[NST], s_ch[NST], s_lds[NST];
+    auto dy_of = [](int v) { return v >> 16; };
+    auto dx_of = [](int v) { return (int)(short)(v & 0xffff); };
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int e = tid + i * 256;
         const int c4 = e & 3;
         if (RES == NGAN_RESAMPLE_UP2) {
             const int pp = (e >> 2) % NPP, g = (e >> 2) / NPP;
-            s_dy[i] = pp / PW - 1; s_dx[i] = pp % PW - 1; s_ch[i] = g * 16 + c4 * 4;
+            s_dyx[i] = ((pp / PW - 1) << 16) | ((pp % PW - 1) & 0xffff); s_ch[i] = g * 16 + c4 * 4;
             s_lds[i] = e * 4;                                   // patch is plain [g][py][px][16]
         } else {
             const int pix = (e >> 2) % NPIX, g = (e >> 2) / NPIX;
             const int ty = pix / HW_, tx = pix % HW_;
-            s_dy[i] = ty - 1; s_dx[i] = tx - 1; s_ch[i] = g * 16 + c4 * 4;
+            s_dyx[i] = ((ty - 1) << 16) | ((tx - 1) & 0xffff); s_ch[i] = g * 16 + c4 * 4;
             s_lds[i] = PREC ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx)
                             : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
         }
@@ -444,7 +485,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
     int s_off[NST];      // tile-invariant part of the byte offset (plain input); bilinear input: channel byte offset
 #pragma unroll
     for (int i = 0; i < NST; ++i)
-        s_off[i] = RES == NGAN_RESAMPLE_UP2 ? s_ch[i] * 4 : ((s_dy[i] * a.W + s_dx[i]) * K + s_ch[i]) * 4;
+        s_off[i] = RES == NGAN_RESAMPLE_UP2 ? s_ch[i] * 4 : ((dy_of(s_dyx[i]) * a.W + dx_of(s_dyx[i])) * K + s_ch[i]) * 4;
     auto issue = [&](int tt) {
         int b, y0, x0;
         decode(tt, b, y0, x0);
@@ -454,7 +495,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             const int ly0 = y0 >> 1, lx0 = x0 >> 1;
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
-                const int ly = min(max(ly0 + s_dy[i], 0), h - 1), lx = min(max(lx0 + s_dx[i], 0), w - 1);
+                const int ly = min(max(ly0 + dy_of(s_dyx[i]), 0), h - 1), lx = min(max(lx0 + dx_of(s_dyx[i]), 0), w - 1);
                 const unsigned off = (tid + i * 256 < N_SRC) ? (unsigned)((ly * w + lx) * K * 4 + s_off[i]) : OOB;
                 stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
             }
@@ -462,9 +503,13 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             const int tile_off = (y0 * a.W + x0) * K * 4;
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
-                const bool ok = (tid + i * 256 < N_SRC) && (unsigned)(y0 + s_dy[i]) < (unsigned)a.H && (unsigned)(x0 + s_dx[i]) < (unsigned)a.W;
+                const bool ok = (tid + i * 256 < N_SRC) && (unsigned)(y0 + dy_of(s_dyx[i])) < (unsigned)a.H && (unsigned)(x0 + dx_of(s_dyx[i])) < (unsigned)a.W;
                 const unsigned off = ok ? (unsigned)(tile_off + s_off[i]) : OOB;
+#if defined(NGAN_EXP) && (NGAN_EXP & 2)
+                stg[i] = make_float4((float)off, 1.f, 2.f, 3.f);          // timing experiment: no global loads
+#else
                 stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+#endif
             }
         }
     };
@@ -481,7 +526,9 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
     while (t < t_end) {
         int b, y0, x0;
         decode(t, b, y0, x0);
+#if !(defined(NGAN_EXP) && (NGAN_EXP & 16))
         __syncthreads();   // previous tile's MFMAs have finished reading `tile`
+#endif
         if (RES == NGAN_RESAMPLE_UP2) {
 #pragma unroll
             for (int i = 0; i < NST; ++i)
@@ -507,13 +554,19 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         } else {
 #pragma unroll
             for (int i = 0; i < NST; ++i)
+#if defined(NGAN_EXP) && (NGAN_EXP & 8)
+                if (tid + i * 256 < N_SRC && stg[i].y == 77.f) {          // timing experiment: the staging stores never execute
+#else
                 if (tid + i * 256 < N_SRC) {
+#endif
                     if (PREC) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
                     else st4(&tile[s_lds[i]], stg[i]);
                 }
         }
+#if !(defined(NGAN_EXP) && (NGAN_EXP & 16))
         __syncthreads();
-        const int tn = t + nper;
+#endif
+        const int tn = t + run.step;
         if (tn < t_end) issue(tn);   // in flight while this tile is computed
         // PixelNorm-backward epilogue: its operands (this tile's pixels of the producer's output and norm) are requested now,
         // so that they arrive during the MFMAs instead of stalling the epilogue
@@ -587,6 +640,16 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             }
         }
         }
+#if defined(NGAN_EXP) && (NGAN_EXP & 4)
+        {   // timing experiment: no epilogue; the accumulators are consumed by a store that never happens
+            float sum = 0.f;
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) sum += acc[pg][mt][0] + acc[pg][mt][1] + acc[pg][mt][2] + acc[pg][mt][3];
+            if (sum == 123.456f) a.y[tid] = sum;
+        }
+#else
         // ---- epilogue (same math as conv3x3_kernel with WN = 1; reciprocal square root instead of sqrt + divide) ----
         const long img = (long)b * a.H * a.W;
         float timg = 0.f;
@@ -668,7 +731,11 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             if (OUTMODE == 0) {
                 if (EPI != EPI_TO_IMAGE || a.y) {
                     // stores through the output image's descriptor: an invalid (off-image) pixel gets an out-of-range offset
+#if defined(NGAN_EXP) && (NGAN_EXP & 1)
+                    const unsigned off = (valid && v[0].x == 123.456f) ? (unsigned)(((gy * a.W + gx) * N + q * 4) * 4) : OOB;   // timing experiment: no stores land
+#else
                     const unsigned off = valid ? (unsigned)(((gy * a.W + gx) * N + q * 4) * 4) : OOB;
+#endif
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[mt]), y_rsrc, off + (valid ? mt * 64 : 0), 0, 0);
@@ -724,8 +791,15 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             const float tv = tanhf(timg);
             if (q < PGW && gy < a.H && gx < a.W) a.aout[img + (long)gy * a.W + gx] = tv;
         }
+#endif
         t = tn;
     }
+#ifdef NGAN_CLOCK_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        g_clock_stamps[blockIdx.x * 4 + 0] = clk0; g_clock_stamps[blockIdx.x * 4 + 1] = rt0;
+        g_clock_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime(); g_clock_stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -761,10 +835,9 @@ __global__ __launch_bounds__(256, KG == 1 ? 3 : 2) void conv3x3_up2f_kernel(Conv
             wlo[st] = __builtin_bit_cast(bf16x8, l4);
         }
     }
-    const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
-    const int band = (n_tiles + 7) >> 3;
-    const int t_end = min((xcd + 1) * band, n_tiles);
-    int t = xcd * band + (blockIdx.x >> 3);
+    const TileRun run = tile_run(n_tiles);
+    int t = run.t;
+    const int t_end = run.t_end;
 
     int s_ty[NST], s_tx[NST], s_ch[NST], s_lds[NST];
 #pragma unroll
@@ -820,7 +893,7 @@ __global__ __launch_bounds__(256, KG == 1 ? 3 : 2) void conv3x3_up2f_kernel(Conv
         for (int i = 0; i < NST; ++i)
             if (tid + i * 256 < N_SRC) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
         __syncthreads();
-        const int tn = t + nper;
+        const int tn = t + run.step;
         issue(min(tn, t_end - 1));   // in flight while this tile is computed
         __builtin_amdgcn_sched_barrier(0);   // (the scheduler would otherwise sink the loads to their first use, behind the MFMAs)
         f32x4 acc[4];
@@ -961,10 +1034,7 @@ int launch_up2f(ConvArgs a, hipStream_t s) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_up2f_kernel<KG, EPI>, 256, 0) != hipSuccess || n < 1) n = 1;
         per_cu = n > 4 ? 4 : n;
     }
-    int grid = 256 * per_cu;
-    if (grid > n_tiles) grid = n_tiles;
-    grid &= ~7;
-    if (grid < 8) grid = 8;
+    const int grid = persistent_grid(n_tiles, 256 * per_cu);
     hipLaunchKernelGGL((conv3x3_up2f_kernel<KG, EPI>), dim3(grid), dim3(256), 0, s, a, n_tiles);
     return ngan::launch_status("ngan_conv3x3_fwd(bilinear folded)");
 }
@@ -996,10 +1066,7 @@ int launch_persist(ConvArgs a, hipStream_t s) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_persist_kernel<MTW, KG, RES, EPI, OUTMODE, PREC>, 256, 0) != hipSuccess || n < 1) n = 1;
         per_cu = n > 4 ? 4 : n;
     }
-    int grid = 256 * per_cu;
-    if (grid > n_tiles) grid = n_tiles;
-    grid &= ~7;
-    if (grid < 8) grid = 8;
+    const int grid = persistent_grid(n_tiles, 256 * per_cu);
     hipLaunchKernelGGL((conv3x3_persist_kernel<MTW, KG, RES, EPI, OUTMODE, PREC>), dim3(grid), dim3(256), 0, s, a, n_tiles);
     return ngan::launch_status("ngan_conv3x3_fwd(persistent)");
 }
@@ -1730,6 +1797,12 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     }
     return NGAN_OK;
 }
+
+#ifdef NGAN_CLOCK_PROBE
+extern "C" int ngan_debug_clock_stamps(unsigned long long* host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_stamps), sizeof(unsigned long long) * 4 * n_blocks, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int resample, int precision, char* buf, int len) {
     NGAN_REQUIRE(buf && len > 0, NGAN_ERR_ARG, "conv3x3_wgrad_kernel_name: bad buffer");

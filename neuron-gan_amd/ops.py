@@ -273,11 +273,16 @@ class deferred_wgrad:
 
 
 def flush_wgrad():
+    """Reduce every pending slab set.  The contributions to one gradient are summed in a CANONICAL order (by the role of the node
+    that produced them, then by arrival), not in the order autograd happened to run the nodes: that order is not reproducible for a
+    double-backward graph (autograd numbers nodes per thread, and the nodes a create_graph pass creates on the engine's thread are
+    numbered independently of the forward nodes created on the caller's thread, so their relative priority drifts from one
+    iteration to the next) and a floating-point sum depends on it in the last bit."""
     if not _pending:
         return 0
     rec, n = b"", 0
     for e in _pending.values():
-        src = e["sources"]
+        src = sorted(e["sources"], key=lambda s: s[3])        # stable: equal roles keep their arrival order
         for first in range(0, len(src), 4):            # at most 4 slab sets per record; further records accumulate
             part = src[first:first + 4]
             ptrs = [s[0].data_ptr() for s in part] + [0] * (4 - len(part))
@@ -292,7 +297,8 @@ def flush_wgrad():
     return n
 
 
-def _run_wgrad(x, g, resample, scale, accumulate_into=None):
+def _run_wgrad(x, g, resample, scale, accumulate_into=None, role=0):
+    """role: 0 = weight gradient of a forward conv node, 1 = of an input-gradient node (ConvDgrad.backward); see flush_wgrad"""
     b, h, w, cout = g.shape
     cin = x.shape[3]
     gw = accumulate_into if accumulate_into is not None else torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
@@ -301,7 +307,7 @@ def _run_wgrad(x, g, resample, scale, accumulate_into=None):
         _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 2, _conv_precision)
         plan = _C.wgrad_plan(b, h, w, cin, cout)
         e = _pending.setdefault(gw.data_ptr(), dict(gw=gw, plan=plan, cin=cin, sources=[]))
-        e["sources"].append((ws, plan[0], float(scale)))
+        e["sources"].append((ws, plan[0], float(scale), role))
         return gw
     _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 1 if accumulate_into is not None else 0,
             _conv_precision)
@@ -488,7 +494,7 @@ class ConvDgrad(Function):
         gw = None
         if ctx.needs_input_grad[1]:
             if _accumulates_in_place(weight):
-                _run_wgrad(_c(h), g, resample, scale, accumulate_into=weight.grad)
+                _run_wgrad(_c(h), g, resample, scale, accumulate_into=weight.grad, role=1)
             else:
                 gw = ConvWgrad.apply(h, g, resample, scale)
         return gg, gw, None, None

@@ -321,9 +321,15 @@ class PGGANTrainer:
             fakes = self.G(torch.cat(zs, dim=0) if with_gp else zs[0])
         loss, s_real, s_fake = self.d_loss(real, fake_images=fakes[:b])  # train.py:358
         gp = self.gp_loss(real, x_tilde=fakes[b:] if with_gp else None, epsilon=eps)  # train.py:361
-        loss = loss + gp  # train.py:362
+        # train.py:362, 365: D_loss += gp; D_loss.backward().  The two terms share no graph node (separate critic passes), so the sum's
+        # backward is the two backwards; they run one after the other so that every critic parameter receives its contributions in
+        # a fixed order (penalty terms, then the W-loss term): autograd's node order inside ONE run over both graphs is not
+        # reproducible from iteration to iteration (ops.flush_wgrad), and the step driver is meant to be bit-reproducible.
         with ops.deferred_wgrad():   # weight-gradient slabs of the whole pass are reduced by one launch at the end
-            loss.backward()  # train.py:365
+            if gp.requires_grad:
+                gp.backward()
+            loss.backward()
+        loss = loss.detach() + gp.detach()
         return {"D_loss": loss.detach(), "score_real": s_real.detach(), "score_fake": s_fake.detach(), "D_grad_pen": gp.detach()}
 
     def d_step(self, real, z_d=None, z_gp=None, eps=None):
@@ -445,7 +451,11 @@ class PGGANTrainer:
         self.opt_g.repack()       # steps find them complete
         ops.refresh_packed()      # (copies of tensors that belong to neither optimiser)
         torch.cuda.synchronize()
-        mode = os.environ.get("NGAN_CAPTURE_MODE", "global")
+        # With an RCCL process group alive its watchdog thread polls collective events (hipEventQuery) at any time.  HIP's GLOBAL
+        # capture mode refuses such a call from ANY thread while a capture is active (hipErrorStreamCaptureUnsupported -> the
+        # watchdog terminates the process); thread_local polices the capturing thread only.  The second rule (an event whose stream
+        # is part of the capture) is what _on_comm_stream takes care of.  Both reproduced case by case: tools/capture_event_probe.py.
+        mode = os.environ.get("NGAN_CAPTURE_MODE") or ("thread_local" if self._comm_stream is not None else "global")
         if not segmented:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode=mode):

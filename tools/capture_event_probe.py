@@ -13,7 +13,10 @@ just before a capture is a time bomb with a ~100 ms fuse.
 Each case runs in a child process (an abort is the expected outcome of some), exactly once:
     work_stream/global        collective on the stream that later joins the capture, default capture mode      -> expect ABORT
     work_stream/thread_local  the same in thread_local capture mode (does the mode matter for this rule?)
-    comm_stream/global        collective on a dedicated stream that never takes part in a capture (the fix)    -> expect survive
+    comm_stream/global        collective on a dedicated stream that never takes part in a capture: the event rule no longer
+                              applies, but in GLOBAL capture mode HIP refuses hipEventQuery from ANY thread while a capture is
+                              active (hipErrorStreamCaptureUnsupported)                                        -> expect ABORT
+    comm_stream/thread_local  dedicated stream + thread_local capture mode (the fix: both rules satisfied)    -> expect survive
 Run on the GPU box:  python tools/capture_event_probe.py
 """
 import os
@@ -60,7 +63,7 @@ if __name__ == "__main__":
     if len(sys.argv) == 3:
         child(sys.argv[1], sys.argv[2])
         sys.exit(0)
-    for where, mode in (("work_stream", "global"), ("work_stream", "thread_local"), ("comm_stream", "global")):
+    for where, mode in (("work_stream", "global"), ("work_stream", "thread_local"), ("comm_stream", "global"), ("comm_stream", "thread_local")):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), where, mode], capture_output=True, text=True, timeout=300)
         tail = [ln for ln in (r.stdout + r.stderr).splitlines() if "hipError" in ln or "SURVIVED" in ln or "terminate" in ln]
         print(f"case {where}/{mode}: rc={r.returncode} " + ("SURVIVED" if "SURVIVED" in r.stdout else "ABORTED") + " | " + " | ".join(t[:160] for t in tail[:3]),
