@@ -327,6 +327,8 @@ __device__ __forceinline__ TileRun tile_run(int n_tiles) {      // this workgrou
 }
 
 inline int persistent_grid(int n_tiles, int resident) {
+    static const int cap = [] { const char* e = getenv("NGAN_PERSIST_WG_PER_CU"); const int n = e ? atoi(e) : 0; return n > 0 ? n * 256 : 1 << 30; }();   // (A/B switch)
+    if (resident > cap) resident = cap;
     int grid = resident < n_tiles ? resident : n_tiles;
     grid &= ~7;
     return grid < 8 ? 8 : grid;
@@ -661,6 +663,8 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         }
         // PixelNorm-backward operands that were not prefetched: all of the tile's loads before its first store (a load issued behind a
         // store can only be awaited by draining that store, see pin_registers)
+        // (operands of the PixelNorm-backward epilogue must have landed before the first store is issued: conv3x3_tile_kernel)
+        if (EPI == EPI_PN_BWD && OUTMODE == 0 && PRE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         constexpr bool LATE = EPI == EPI_PN_BWD && OUTMODE == 0 && !PRE;
         float4 yy_epi[LATE ? PGW : 1][MTW];
         float rn_epi[LATE ? PGW : 1];
@@ -674,6 +678,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 for (int mt = 0; mt < MTW; ++mt) yy_epi[pg][mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
                 rn_epi[pg] = a.arn[pix];
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg) {
@@ -755,6 +760,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                         for (int mt = 0; mt < MTW; ++mt) yy4[sub][mt] = ld4(a.ay + pix * N + mt * 16 + q * 4);
                         rr4[sub] = a.arn[pix];
                     }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
@@ -790,6 +796,423 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             const int gy = y0 + row, gx = x0 + col;
             const float tv = tanhf(timg);
             if (q < PGW && gy < a.H && gx < a.W) a.aout[img + (long)gy * a.W + gx] = tv;
+        }
+#endif
+        t = tn;
+    }
+#ifdef NGAN_CLOCK_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        g_clock_stamps[blockIdx.x * 4 + 0] = clk0; g_clock_stamps[blockIdx.x * 4 + 1] = rt0;
+        g_clock_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime(); g_clock_stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv3x3_tile_kernel: the persistent kernel for plain (not resampled) input on images whose width is a multiple of the 32-pixel
+// tile, rebuilt around one measurement (tools/clock_probe.py + the NGAN_EXP builds): v_mfma_f32_16x16x4_f32 runs on the vector
+// FMA lanes, so every VALU instruction any wave of the SIMD issues is 4 cycles the matrix instructions do not get -- the fp32
+// 16 -> 16 layer spent 190 VALU instructions per 144 MFMAs of a wave's tile, 80 of them integer address / bounds arithmetic.
+// Here the per-tile arithmetic is scalar:
+//   * tile loads: per-lane byte offsets are tile-invariant constants; the tile moves the descriptor's BASE (64-bit SALU add), and
+//     conv padding is done by whole load instructions -- the staging order puts the 32 interior columns into LPG loads per channel
+//     group and the two halo columns into one extra load, so the top halo row is "load 0 of waves 0-1" (a zero-record descriptor
+//     when the tile touches the image top), the bottom is the descriptor's range check, and left / right only touch the halo load
+//     (a 3-instruction lane select);
+//   * output stores, PixelNorm-backward operand loads, norms: constant per-lane offsets + a scalar tile offset (one v_add each);
+//   * the bias is the accumulators' initial value (C operand of the first MFMA), the epilogue arithmetic is written on float2 so
+//     that it compiles to packed v_pk_mul / v_pk_fma.
+// Same LDS image and MFMA order as conv3x3_persist_kernel; bit-identical to it without a bias (with one, the bias is added first
+// instead of last).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef NGAN_TILE_PRE
+#define NGAN_TILE_PRE 1
+#endif
+
+template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
+__global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_tile_kernel(ConvArgs a, int n_tiles) {
+#ifdef NGAN_CLOCK_PROBE
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr int THc = persist_tile_h(MTW, KG, 0), PGW = THc / 2, RPW = THc / 4;
+    constexpr int HH_ = THc + 2, LP = 40;
+    constexpr int NSTEP = KG == 1 ? 5 : 9;
+    constexpr int W_ELEMS = PREC ? NSTEP * MTW * 2 * 256 : 9 * KG * MTW * 256, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int LPG = HH_ / 2;                 // interior loads per 16-channel group: HH_ rows x 32 columns x 4 quads / 256 threads
+    constexpr int NL = KG * LPG, NST = NL + 1;   // + one load for the two halo columns
+    constexpr int N_HALO = KG * 2 * HH_ * 4;     // its active lanes: (group, side, row, quad)
+    constexpr int K = KG * 16, N = MTW * 16;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    static_assert(HH_ % 2 == 0 && N_HALO <= 256, "staging layout");
+    __shared__ __attribute__((aligned(16))) float smem[W_ELEMS + TILE_ELEMS];
+    float* wl = smem;
+    float* tile = smem + W_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+
+    for (int e = tid; e < W_ELEMS / 4; e += 256) st4(wl + e * 4, ld4(a.wp + e * 4));
+
+    const TileRun run = tile_run(n_tiles);
+    int t = run.t;
+    const int t_end = run.t_end;
+
+    auto lds_slot = [&](int g, int c4, int ty, int tx) {
+        return PREC ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx) : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+    };
+    // ---- tile-invariant staging constants: byte offset from the halo origin (y0 - 1, x0 - 1), LDS float index ----
+    unsigned s_voff[NST];
+    int s_lds[NST];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int g = i / LPG, e = tid + (i % LPG) * 256;
+        const int c4 = e & 3, pix = e >> 2, ty = pix >> 5, tx = (pix & 31) + 1;
+        s_voff[i] = (unsigned)(((ty * a.W + tx) * K + g * 16 + c4 * 4) * 4);
+        s_lds[i] = lds_slot(g, c4, ty, tx);
+    }
+    int h_bits;                                   // halo load: 1 = left column, 2 = right column, 4 = top row, 8 = unused lane
+    {
+        const int c4 = tid & 3, r = (tid >> 2) % HH_, sg = (tid >> 2) / HH_, side = sg & 1, g = sg >> 1;
+        const bool used = tid < N_HALO;
+        const int tx = side ? 33 : 0;
+        s_voff[NL] = used ? (unsigned)(((r * a.W + tx) * K + (used ? g : 0) * 16 + c4 * 4) * 4) : OOB;
+        s_lds[NL] = lds_slot(used ? g : 0, c4, r, tx);
+        h_bits = used ? ((side ? 2 : 1) | (r == 0 ? 4 : 0)) : 8;
+    }
+    int rd[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) rd[dx] = (p + dx) * 16 + ((q ^ ((((p + dx) >> 2) & 1) << 1)) << 2);
+    int rs[PREC ? NSTEP : 1];
+    if (PREC) {
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            int tap = KG == 1 ? 2 * st + (q >> 1) : st;
+            if (tap > 8) tap = 8;                                  // zero-weight padding tap: any valid address
+            const int dy = tap / 3, dx = tap % 3;
+            const int slot = (KG == 1 ? (q & 1) : q) ^ ((((p + dx) >> 2) & 1) << 1);
+            rs[st] = (dy * LP + p + dx) * 16 + slot * 4;
+        }
+    }
+    // ---- tile-invariant epilogue constants: this lane's output byte offsets from the tile origin ----
+    constexpr int OS = OUTMODE ? 2 : 1;            // the pool-adjoint store writes a 2x2 block of a (2H, 2W) tensor per computed pixel
+    const int Wo = OS * a.W;
+    unsigned e_voff[PGW];
+#pragma unroll
+    for (int pg = 0; pg < PGW; ++pg) {
+        const int row = wave * RPW + (pg >> 1), col = (pg & 1) * 16 + p;
+        e_voff[pg] = (unsigned)((((OS * row) * Wo + OS * col) * N + q * 4) * 4);
+    }
+    constexpr int NSHIFT = MTW == 1 ? 4 : 5;       // pixel index * 4 bytes = (e_voff - 16 q) / N
+    unsigned t_voff = 0;                           // ToImage: lane group q finishes pixel group q
+    if (EPI == EPI_TO_IMAGE) t_voff = (unsigned)(((wave * RPW + (q >> 1)) * a.W + (q & 1) * 16 + p) * 4);
+
+    auto decode = [&](int tt, int& b, int& y0, int& x0) {
+        const int txi = tt % a.tiles_x; tt /= a.tiles_x;
+        const int tyi = tt % a.tiles_y;
+        b = tt / a.tiles_y;
+        y0 = tyi * THc; x0 = txi * 32;
+    };
+    const unsigned img_bytes = (unsigned)(a.H * a.W * K) * 4u;
+    float4 stg[NST];
+    auto issue = [&](int tt) {
+        int b, y0, x0;
+        decode(tt, b, y0, x0);
+        const int soff = ((y0 - 1) * a.W + (x0 - 1)) * K * 4;                 // negative on the top row / for the first tile
+        const char* base = reinterpret_cast<const char*>(a.x + (long)b * a.H * a.W * K) + soff;
+        const unsigned nrec = img_bytes - (unsigned)soff;                     // bytes from `base` to the end of the image
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, nrec, 0x00020000);
+        // the top halo row is the first interior load of waves 0 and 1 (+ flagged lanes of the halo load): above the image it reads
+        // through a descriptor with no records, i.e. zeros
+        const __amdgpu_buffer_rsrc_t rsrc_top = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (y0 == 0 && wave < 2) ? 0u : nrec, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+#if defined(NGAN_EXP) && (NGAN_EXP & 2)
+            stg[i] = make_float4((float)s_voff[i], 1.f, 2.f, 3.f);          // timing experiment: no global loads
+#else
+            stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128((i % LPG == 0) ? rsrc_top : rsrc, s_voff[i], 0, 0));
+#endif
+        }
+        const int bad = (x0 == 0 ? 1 : 0) | (x0 + 32 >= a.W ? 2 : 0) | (y0 == 0 ? 4 : 0) | 8;
+        const unsigned hoff = (h_bits & bad) ? OOB : s_voff[NL];
+#if defined(NGAN_EXP) && (NGAN_EXP & 2)
+        stg[NL] = make_float4((float)hoff, 1.f, 2.f, 3.f);
+#else
+        stg[NL] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, hoff, 0, 0));
+#endif
+    };
+    if (t < t_end) issue(t);
+#if defined(NGAN_EXP) && (NGAN_EXP & 32)
+    {   // timing experiment: stagger the workgroups that (probably) share a CU by a quarter of a tile round each
+        const int k = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < k * 10; ++i) __builtin_amdgcn_s_sleep(8);        // 10 x 8 x 64 cycles = 5120 cycles per step
+    }
+#endif
+
+    f32x4 bvec[MTW];
+    float4 wimg[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const float4 b4 = a.bias ? ld4(a.bias + mt * 16 + q * 4) : f4zero();
+        bvec[mt] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+        wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + mt * 16 + q * 4) : f4zero();
+    }
+    const float inv_n = 1.0f / (float)N;
+    const f32x2 slope2 = {a.slope, a.slope};
+
+    while (t < t_end) {
+        int b, y0, x0;
+        decode(t, b, y0, x0);
+#if !(defined(NGAN_EXP) && (NGAN_EXP & 16))
+        __syncthreads();   // previous tile's MFMAs have finished reading `tile`
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // timing experiment: no workgroup barrier (wrong results)
+#endif
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            if (PREC) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
+            else st4(&tile[s_lds[i]], stg[i]);
+        }
+        if (tid < N_HALO) {
+            if (PREC) st_split<KG, PLANE>(tile, s_lds[NL], stg[NL]);
+            else st4(&tile[s_lds[NL]], stg[NL]);
+        }
+#if !(defined(NGAN_EXP) && (NGAN_EXP & 16))
+        __syncthreads();
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // timing experiment: no workgroup barrier (wrong results)
+#endif
+        const int tn = t + run.step;
+        if (tn < t_end) issue(tn);   // in flight while this tile is computed
+
+        // ---- per-tile scalars of the epilogue.  The tile's byte offset is ADDED to the per-lane constants (one v_add per access)
+        // instead of riding in the buffer instructions' soffset field: a buffer_store_dwordx4 with an SGPR soffset reads its data
+        // registers late, the compiler (whose hazard table exempts exactly that form) puts no wait state behind it, and the next
+        // VALU write into those registers reached memory instead -- single components of the last four lanes of a pixel group,
+        // in a fraction of a percent of the tiles (tools/dbg_tile.py; found the same way: bit-comparison with the old kernel) ----
+        const long img = (long)b * a.H * a.W;
+        const int pix0 = (OS * y0) * Wo + OS * x0;                       // first output pixel of the tile inside its image
+        const unsigned y_soff = (unsigned)pix0 * (N * 4), p_soff = (unsigned)(y0 * a.W + x0) * 4u;
+        const unsigned out_bytes = (unsigned)(OS * a.H * Wo * N) * 4u, px_bytes = (unsigned)(a.H * a.W) * 4u;
+        __amdgpu_buffer_rsrc_t y_rsrc, rn_rsrc, ay_rsrc, arn_rsrc;
+        if (EPI != EPI_TO_IMAGE || a.y) {
+            y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img * (OS * OS) * N, 0, out_bytes, 0x00020000);
+            if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE) rn_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rn + img, 0, px_bytes, 0x00020000);
+        }
+        if (EPI == EPI_PN_BWD) {
+            ay_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ay) + img * (OS * OS) * N, 0, out_bytes, 0x00020000);
+            arn_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.arn) + img * (OS * OS), 0, (unsigned)(OS * a.H * Wo) * 4u, 0x00020000);
+        }
+        // PixelNorm-backward operands (same shape as the output): requested before the MFMAs where registers allow, else before the
+        // first store of the epilogue (a load issued behind a store can only be awaited by draining that store)
+        constexpr bool PNB = EPI == EPI_PN_BWD && OUTMODE == 0;
+        constexpr bool PRE = PNB && MTW * KG > 1 && NGAN_TILE_PRE;
+        float4 yy[PNB ? PGW : 1][MTW];
+        float rr[PNB ? PGW : 1];
+        auto load_pn_operands = [&]() {
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+                    yy[PNB ? pg : 0][mt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ay_rsrc, e_voff[pg] + y_soff + mt * 64, 0, 0));
+                rr[PNB ? pg : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arn_rsrc, ((e_voff[pg] - q * 16) >> NSHIFT) + p_soff, 0, 0));
+            }
+        };
+        if (PRE) load_pn_operands();
+
+        f32x4 acc[PGW][MTW];
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = bvec[mt];       // the bias: C operand of the first MFMA
+        if (PREC) {
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                bf16x8 xh[PGW], xl[PGW];
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) {
+                    const int row = wave * RPW + (pg >> 1);
+                    const int base = (row * LP + (pg & 1) * 16) * 16 + rs[st];
+                    xh[pg] = *reinterpret_cast<const bf16x8*>(&tile[base]);
+                    xl[pg] = *reinterpret_cast<const bf16x8*>(&tile[KG == 1 ? (base ^ 8) : (base + PLANE)]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wl[((st * MTW + mt) * 2 + 0) * 256 + lane * 4]);
+                    const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&wl[((st * MTW + mt) * 2 + 1) * 256 + lane * 4]);
+#pragma unroll
+                    for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[pg], acc[pg][mt], 0, 0, 0);
+#pragma unroll
+                    for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[pg], acc[pg][mt], 0, 0, 0);
+#pragma unroll
+                    for (int pg = 0; pg < PGW; ++pg) acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[pg], acc[pg][mt], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    float xv[PGW][4];
+#pragma unroll
+                    for (int pg = 0; pg < PGW; ++pg) {
+                        const int row = wave * RPW + (pg >> 1);
+                        float4 v = ld4(&tile[g * PLANE + ((row + dy) * LP + (pg & 1) * 16) * 16 + rd[dx]]);
+                        xv[pg][0] = v.x; xv[pg][1] = v.y; xv[pg][2] = v.z; xv[pg][3] = v.w;
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        const float4 wv4 = ld4(&wl[((tap * KG + g) * MTW + mt) * 256 + lane * 4]);
+                        const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int pg = 0; pg < PGW; ++pg)
+                                acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i], xv[pg][i], acc[pg][mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#if defined(NGAN_EXP) && (NGAN_EXP & 4)
+        {   // timing experiment: no epilogue; the accumulators are consumed by a store that never happens
+            float sum = 0.f;
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) sum += acc[pg][mt][0] + acc[pg][mt][1] + acc[pg][mt][2] + acc[pg][mt][3];
+            if (sum == 123.456f) a.y[tid] = sum;
+        }
+#else
+        // ---- epilogue ----
+        if (PNB && !PRE) load_pn_operands();
+        // PixelNorm-backward operands: wait for everything in flight (the operand loads and the next tile, issued a tile's worth of
+        // MFMAs ago) BEFORE the first store goes out.  Once stores are in flight, loads and stores of gfx9 retire out of order with each other
+        // under one counter, and the counted waits the compiler emits for the older loads returned early: wrong last dwords in the
+        // last lanes of a pixel group (tools/dbg_epi2.py; without the prefetch the kernel is bit-identical to conv3x3_persist_kernel)
+        if (PNB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float timg = 0.f;
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg) {
+            f32x2 lo[MTW], hi[MTW];                 // channels (4q, 4q+1) and (4q+2, 4q+3) of each 16-channel tile
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                lo[mt] = (f32x2){acc[pg][mt][0], acc[pg][mt][1]};
+                hi[mt] = (f32x2){acc[pg][mt][2], acc[pg][mt][3]};
+            }
+            if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE) {
+                f32x2 sq = {0.f, 0.f};
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const f32x2 sl = lo[mt] * slope2, sh = hi[mt] * slope2;            // LeakyReLU, 0 <= slope <= 1 (fmaxf: one v_max each;
+                    lo[mt] = (f32x2){fmaxf(lo[mt].x, sl.x), fmaxf(lo[mt].y, sl.y)};     //  __builtin_elementwise_max adds a canonicalising v_max)
+                    hi[mt] = (f32x2){fmaxf(hi[mt].x, sh.x), fmaxf(hi[mt].y, sh.y)};
+                    sq = mt == 0 ? lo[mt] * lo[mt] : __builtin_elementwise_fma(lo[mt], lo[mt], sq);
+                    sq = __builtin_elementwise_fma(hi[mt], hi[mt], sq);
+                }
+                float ss = sq.x + sq.y;
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                const float m = ss * inv_n + a.eps;
+                const float inv = __builtin_amdgcn_rsqf(m);
+                const f32x2 inv2 = {inv, inv};
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) { lo[mt] *= inv2; hi[mt] *= inv2; }
+                if ((EPI == EPI_LRELU_PN || a.y) && q == 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m * inv), rn_rsrc, (e_voff[pg] >> NSHIFT) + p_soff, 0, 0);
+            }
+            if (EPI == EPI_TO_IMAGE) {
+                f32x2 d2 = {0.f, 0.f};
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    d2 = __builtin_elementwise_fma(lo[mt], (f32x2){wimg[mt].x, wimg[mt].y}, d2);
+                    d2 = __builtin_elementwise_fma(hi[mt], (f32x2){wimg[mt].z, wimg[mt].w}, d2);
+                }
+                float d = d2.x + d2.y;
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+                if (q == pg) timg = d;          // all four q-lanes hold pixel group pg's sum; lane group q keeps the one it will finish
+            }
+            if (PNB) {
+                // backward of the LeakyReLU -> PixelNorm that produced this layer's input, applied to the gradient just computed
+                float s = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const float4 y4 = yy[PNB ? pg : 0][mt];
+                    s += lo[mt].x * y4.x + lo[mt].y * y4.y + hi[mt].x * y4.z + hi[mt].y * y4.w;
+                }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                s *= inv_n;
+                const float inv_r = 1.0f / rr[PNB ? pg : 0];
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const float4 o = pn_bwd4(make_float4(lo[mt].x, lo[mt].y, hi[mt].x, hi[mt].y), yy[PNB ? pg : 0][mt], s, inv_r, a.slope);
+                    lo[mt] = (f32x2){o.x, o.y}; hi[mt] = (f32x2){o.z, o.w};
+                }
+            }
+            if (OUTMODE == 0) {
+                if (EPI != EPI_TO_IMAGE || a.y) {
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        const u32x4 v = __builtin_bit_cast(u32x4, make_float4(lo[mt].x, lo[mt].y, hi[mt].x, hi[mt].y));
+#if defined(NGAN_EXP) && (NGAN_EXP & 1)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, y_rsrc, lo[0].x == 123.456f ? e_voff[pg] + y_soff + mt * 64 : OOB, 0, 0);
+#else
+                        __builtin_amdgcn_raw_buffer_store_b128(v, y_rsrc, e_voff[pg] + y_soff + mt * 64, 0, 0);
+#endif
+                    }
+                }
+            } else {
+                // pool-adjoint store: the value * 0.25 goes to the 2x2 block (2gy + i, 2gx + j); with the PixelNorm-backward epilogue
+                // each of the four pixels has its own operands -- all loads before the first store
+                const unsigned row1 = y_soff + (unsigned)(Wo * N * 4);
+                const unsigned prow1 = (unsigned)pix0 * 4u + (unsigned)(Wo * 4);
+                const f32x2 quarter = {0.25f, 0.25f};
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) { lo[mt] *= quarter; hi[mt] *= quarter; }
+                float4 y4s[EPI == EPI_PN_BWD ? 4 : 1][MTW];
+                float r4s[EPI == EPI_PN_BWD ? 4 : 1];
+                if (EPI == EPI_PN_BWD) {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt)
+                            y4s[sub][mt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ay_rsrc, e_voff[pg] + ((sub >> 1) ? row1 : y_soff) +
+                                                                                                         mt * 64 + (sub & 1) * (N * 4), 0, 0));
+                        r4s[sub] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arn_rsrc, ((e_voff[pg] - q * 16) >> NSHIFT) +
+                                                                                                ((sub >> 1) ? prow1 : (unsigned)pix0 * 4u) + (sub & 1) * 4, 0, 0));
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (loads vs. younger stores: see the plain store path above)
+                }
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    float4 o4[MTW];
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) o4[mt] = make_float4(lo[mt].x, lo[mt].y, hi[mt].x, hi[mt].y);
+                    if (EPI == EPI_PN_BWD) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) s += f4dot(o4[mt], y4s[EPI == EPI_PN_BWD ? sub : 0][mt]);
+                        s += __shfl_xor(s, 16, 64);
+                        s += __shfl_xor(s, 32, 64);
+                        s *= inv_n;
+                        const float inv_r = 1.0f / r4s[EPI == EPI_PN_BWD ? sub : 0];
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) o4[mt] = pn_bwd4(o4[mt], y4s[EPI == EPI_PN_BWD ? sub : 0][mt], s, inv_r, a.slope);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4[mt]), y_rsrc,
+                                                               e_voff[pg] + ((sub >> 1) ? row1 : y_soff) + mt * 64 + (sub & 1) * (N * 4), 0, 0);
+                }
+            }
+        }
+        if (EPI == EPI_TO_IMAGE) {
+            // one tanh per lane instead of four: lane group q finishes pixel group q (same tanhf as the standalone ToImage kernel)
+            const float tv = tanhf(timg);
+            const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.aout + img, 0, px_bytes, 0x00020000);
+            if (q < PGW) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), t_rsrc, t_voff + p_soff, 0, 0);
         }
 #endif
         t = tn;
@@ -1053,8 +1476,30 @@ int dispatch_up2_border(const ConvArgs& a, int epilogue, hipStream_t s) {
     return epilogue ? launch_up2_border<2, EPI_LRELU_PN>(a, s) : launch_up2_border<2, EPI_NONE>(a, s);
 }
 
+inline bool tile_kernel_ok(const ConvArgs& a) {      // conv3x3_tile_kernel: whole tiles along x
+    static const bool off = getenv("NGAN_TILE_KERNEL") && getenv("NGAN_TILE_KERNEL")[0] == '0';     // A/B switch
+    return !off && a.W % 32 == 0;
+}
+
+template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
+int launch_tile(ConvArgs a, hipStream_t s) {
+    a.tiles_x = a.W / 32;
+    a.tiles_y = ngan::ceil_div(a.H, persist_tile_h(MTW, KG, 0));
+    const int n_tiles = a.B * a.tiles_x * a.tiles_y;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_tile_kernel<MTW, KG, EPI, OUTMODE, PREC>, 256, 0) != hipSuccess || n < 1) n = 1;
+        per_cu = n > 4 ? 4 : n;
+    }
+    const int grid = persistent_grid(n_tiles, 256 * per_cu);
+    hipLaunchKernelGGL((conv3x3_tile_kernel<MTW, KG, EPI, OUTMODE, PREC>), dim3(grid), dim3(256), 0, s, a, n_tiles);
+    return ngan::launch_status("ngan_conv3x3_fwd(tile)");
+}
+
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
 int launch_persist(ConvArgs a, hipStream_t s) {
+    if (RES == 0 && tile_kernel_ok(a)) return launch_tile<MTW, KG, EPI, OUTMODE, PREC>(a, s);
     a.tiles_x = ngan::ceil_div(a.W, 32);
     a.tiles_y = ngan::ceil_div(a.H, persist_tile_h(MTW, KG, RES));
     const int n_tiles = a.B * a.tiles_x * a.tiles_y;
@@ -1272,6 +1717,171 @@ __global__ __launch_bounds__(256, (COT * CIT == 1) ? 4 : 2) void wgrad_kernel(Wg
     __syncthreads();
     float* slab = a.partial + ((long)blockIdx.x * gridDim.y + slice) * (9 * CO_S * CI_S);
     for (int e = tid; e < WO * 9 * 64; e += 256) {
+        const int l = e & 63, t = (e >> 6) % 9, o = (e >> 6) / 9;
+        float4 v = red[(o * 9 + t) * 64 + l];               // wave index = wr*WO + wo
+#pragma unroll
+        for (int k = 1; k < WR; ++k) v = f4add(v, red[((k * WO + o) * 9 + t) * 64 + l]);
+        const int ci_l = (o % CIT) * 16 + (l & 15), co_l = (o / CIT) * 16 + 4 * (l >> 4);
+        float* op = slab + ((long)t * CO_S + co_l) * CI_S + ci_l;
+        op[0] = v.x; op[CI_S] = v.y; op[2 * CI_S] = v.z; op[3 * CI_S] = v.w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 weight gradient, second version (wgrad_kernel above: one ds_read_b32 + its address arithmetic per MFMA, 50-55 % of the
+// fp32 MFMA peak).  The contraction index is the pixel, 4 per v_mfma_f32_16x16x4_f32, so an operand register must hold ONE channel
+// of 4 pixels.  The tile is therefore staged channel-major -- gT[co][row][col], xT[ci][row][col + 1 halo] -- with scalar LDS
+// stores (global loads stay 16 B per lane along the channels), and k-lane q of MFMA j takes pixel 16 blk + 4 q + j: the A operands
+// of j = 0..3 are ONE ds_read_b128 of gT, the B operands of all three dx taps of a row are x columns 4q .. 4q + 5 of that row, i.e.
+// one ds_read_b128 + one ds_read_b64, picked by register index j + dx.  36 MFMAs (a 16-pixel block, all 9 taps) need 7 LDS
+// reads and no address arithmetic instead of 40 reads.  Plane pitches are = 4 (mod 64) dwords, which spreads the 16 channel
+// lanes of a read over the banks (one 2-way slot per b128 group) and makes the scalar stores 2-way at worst (free, LDS section of
+// MI355X_MICROARCH.md).  Tile order, per-block slabs and the fixed-order reduction are those of wgrad_kernel: bit-reproducible.
+// NW waves: a 16 x 16 (cout, cin) sub-slice per wave group, the tile's rows split over the groups' waves.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }      // smallest m >= n with m = 4 (mod 64)
+
+template <int COT, int CIT, int RES, int TW, int NW>
+__global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
+    constexpr int NT = NW * 64;
+    constexpr int TH = 256 / TW, HALO_H = TH + 2, NBLK = TW / 16;
+    constexpr int CO_S = COT * 16, CI_S = CIT * 16;
+    constexpr int WO = COT * CIT, WR = NW / WO, RPW = TH / WR;                   // wave groups over sub-slices / over rows
+    constexpr int XP = TW + 4;                                                   // x row pitch (TW + 2 used), a multiple of 4
+    constexpr int PLANE_G = pad_plane(TH * TW), PLANE_X = pad_plane(HALO_H * XP);
+    constexpr int G_ELEMS = CO_S * PLANE_G, X_ELEMS = CI_S * PLANE_X;
+    constexpr int RED_ELEMS = NW * 9 * 64 * 4;
+    constexpr int SMEM = (G_ELEMS + X_ELEMS) > RED_ELEMS ? (G_ELEMS + X_ELEMS) : RED_ELEMS;
+    constexpr int NG = TH * TW * (CO_S / 4) / NT, NXI = HALO_H * (TW + 2) * (CI_S / 4), NX = (NXI + NT - 1) / NT;
+    static_assert(TH * TW * (CO_S / 4) % NT == 0 && TH % WR == 0 && NW % WO == 0, "tile split");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* g_lds = smem;
+    float* x_lds = smem + G_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int wo = wave % WO, wr = wave / WO;
+    const int cot = wo / CIT, cit = wo % CIT;        // this wave's 16x16 (cout, cin) sub-slice, all 9 taps
+    const int slice = blockIdx.y;
+    const int co0 = (slice / a.n_ci_slices) * CO_S, ci0 = (slice % a.n_ci_slices) * CI_S;
+
+    // ---- tile-invariant staging constants: global byte offset inside the image relative to the tile origin, LDS float index ----
+    int g_off[NG], g_l[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int e = tid + i * NT;
+        const int pix = e / (CO_S / 4), c4 = e % (CO_S / 4), r = pix / TW, c = pix % TW;
+        g_off[i] = ((r * a.W + c) * a.N + co0 + c4 * 4) * 4;
+        g_l[i] = (c4 * 4) * PLANE_G + r * TW + c;
+    }
+    int x_r[NX], x_c[NX], x_l[NX];                   // halo pixel (row, col) relative to the tile origin, LDS float index
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int e = tid + i * NT;
+        const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4), r = pix / (TW + 2), c = pix % (TW + 2);
+        x_r[i] = e < NXI ? r - 1 : -1000; x_c[i] = c - 1;
+        x_l[i] = (c4 * 4) * PLANE_X + r * XP + c;
+    }
+    const int x_ch = ci0 + (tid % (CI_S / 4)) * 4;   // (NT is a multiple of CI_S / 4: the channel quad of a thread is the same in every slot)
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 gst[NG], xst[NX];
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int txi = t % a.tiles_x; t /= a.tiles_x;
+        const int tyi = t % a.tiles_y;
+        const int b = t / a.tiles_y;
+        const int y0 = tyi * TH, x0 = txi * TW;
+        // g: the tile origin moves the descriptor's base; rows below the image fall outside its records (zeros), columns right
+        // of the image are masked per lane (only when W is not a multiple of the tile width)
+        {
+            const int soff = (y0 * a.W + x0) * a.N * 4;
+            const char* base = reinterpret_cast<const char*>(a.g + (long)b * a.H * a.W * a.N) + soff;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (unsigned)(a.H * a.W * a.N) * 4u - (unsigned)soff, 0x00020000);
+            const bool ragged = x0 + TW > a.W;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                unsigned off = (unsigned)g_off[i];
+                if (ragged) { const int e = tid + i * NT; if (x0 + (e / (CO_S / 4)) % TW >= a.W) off = OOB; }
+                gst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            }
+        }
+        if (RES == NGAN_RESAMPLE_NONE) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.H * a.W * a.K), 0,
+                                                                                 (unsigned)(a.H * a.W * a.K) * 4u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int gy = y0 + x_r[i], gx = x0 + x_c[i];        // x_r = -1000 marks an unused slot: fails the range test
+                const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.K + x_ch) * 4) : OOB;
+                xst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                xst[i] = x_r[i] > -1000 ? load_resampled<RES>(a.x, b, y0 + x_r[i], x0 + x_c[i], x_ch, a.H, a.W, a.K) : f4zero();
+        }
+    };
+
+    // this lane's operand addresses inside a (row, 16-pixel block): channel plane p of its sub-slice, pixels 4q ..
+    const float* ga = g_lds + (cot * 16 + p) * PLANE_G + 4 * q;
+    const float* xa = x_lds + (cit * 16 + p) * PLANE_X + 4 * q;
+
+    int tile = blockIdx.x;
+    if (tile < a.n_tiles) issue(tile);
+    while (tile < a.n_tiles) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            float* d = g_lds + g_l[i];
+            d[0] = gst[i].x; d[PLANE_G] = gst[i].y; d[2 * PLANE_G] = gst[i].z; d[3 * PLANE_G] = gst[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (x_r[i] > -1000) {
+                float* d = x_lds + x_l[i];
+                d[0] = xst[i].x; d[PLANE_X] = xst[i].y; d[2 * PLANE_X] = xst[i].z; d[3 * PLANE_X] = xst[i].w;
+            }
+        __syncthreads();
+        const int tn = tile + gridDim.x;
+        if (tn < a.n_tiles) issue(tn);   // next tile's loads are in flight during the MFMAs
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wr * RPW + rr;
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) {
+                const float4 av4 = ld4(ga + r * TW + blk * 16);
+                const float av[4] = {av4.x, av4.y, av4.z, av4.w};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float* xr = xa + (r + dy) * XP + blk * 16;
+                    const float4 b0 = ld4(xr);
+                    const float2 b1 = *reinterpret_cast<const float2*>(xr + 4);
+                    const float bv[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y};
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j + dx], acc[dy * 3 + dx], 0, 0, 0);
+                }
+            }
+        }
+        tile = tn;
+    }
+
+    // ---- sum the WR row-waves of each sub-slice through LDS (fixed order), then write this block's slab ----
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        red[(wave * 9 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    float* slab = a.partial + ((long)blockIdx.x * gridDim.y + slice) * (9 * CO_S * CI_S);
+    for (int e = tid; e < WO * 9 * 64; e += NT) {
         const int l = e & 63, t = (e >> 6) % 9, o = (e >> 6) / 9;
         float4 v = red[(o * 9 + t) * 64 + l];               // wave index = wr*WO + wo
 #pragma unroll
@@ -1527,6 +2137,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgradPlan { int co_s, ci_s, nslices, n_ci_slices, tiles_x, tiles_y, n_tiles, nwx, tw; };
+constexpr int wgrad_f32_waves(int cot, int cit) { return cot * cit == 4 ? 8 : 4; }    // a 32 x 32 slice: two waves per 16 x 16 sub-slice
 
 WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
     WgradPlan p;
@@ -1538,7 +2149,8 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
     p.tiles_x = ngan::ceil_div(W, p.tw);
     p.tiles_y = ngan::ceil_div(H, 256 / p.tw);
     p.n_tiles = B * p.tiles_x * p.tiles_y;
-    int cap = 512 / p.nslices;   // about two resident workgroups per CU: few slabs to reduce afterwards (256 / 768 measured slower)
+    static const int total = [] { const char* e = getenv("NGAN_WGRAD_SLABS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 512; }();   // (A/B switch)
+    int cap = total / p.nslices;   // about two resident workgroups per CU: few slabs to reduce afterwards (256 / 768 measured slower)
     if (cap < 1) cap = 1;
     p.nwx = p.n_tiles < cap ? p.n_tiles : cap;
     return p;
@@ -1558,6 +2170,20 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision,
         else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1, 16>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2, 16>), grid, dim3(256), 0, s, a);
         return ngan::launch_status("ngan_conv3x3_wgrad(bf16x3, 16x16 tiles)");
+    }
+    static const bool v1 = getenv("NGAN_WGRAD_V1") && getenv("NGAN_WGRAD_V1")[0] == '1';     // A/B switch: the first fp32 kernel
+    if (!v1) {
+        constexpr int NW = wgrad_f32_waves(COT, CIT);
+        if (p.tw == 32) {
+            if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW>), grid, dim3(NW * 64), 0, s, a);
+            else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 1, 32, NW>), grid, dim3(NW * 64), 0, s, a);
+            else hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 2, 32, NW>), grid, dim3(NW * 64), 0, s, a);
+        } else {
+            if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 16, NW>), grid, dim3(NW * 64), 0, s, a);
+            else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 1, 16, NW>), grid, dim3(NW * 64), 0, s, a);
+            else hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 2, 16, NW>), grid, dim3(NW * 64), 0, s, a);
+        }
+        return ngan::launch_status("ngan_conv3x3_wgrad(f32)");
     }
     if (p.tw == 32) {
         if (res == 0) hipLaunchKernelGGL((wgrad_kernel<COT, CIT, 0, 32>), grid, dim3(256), 0, s, a);
@@ -1785,9 +2411,14 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     const int ci = pick_cfg(mti, B, H, W);
     if (precision == 3)
         snprintf(buf, len, "conv3x3_up2f_kernel<%d, %d>", K / 16, epilogue);
-    else if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0)
-        snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
-                 (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision);
+    else if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0) {
+        if ((out_mode || resample == 0) && W % 32 == 0)
+            snprintf(buf, len, "conv3x3_tile_kernel<%d, %d, %d, %d, %d>", N / 16, K / 16, (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue,
+                     out_mode, precision);
+        else
+            snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
+                     (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision);
+    }
     else if (precision >= 1 && ngan::conv3x3_mid_eligible(B, H, W, precision == 2 ? 32 : K, N))
         return ngan::conv3x3_mid_kernel_name(B, H, W, precision == 2 ? 32 : K, N, resample, epilogue, out_mode, buf, len);
     else {
@@ -1809,7 +2440,8 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_wgrad_kernel_name: bad shape");
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
-    snprintf(buf, len, "%s<%d, %d, %d, %d>", precision == 1 ? "wgrad_bf16x3_kernel" : "wgrad_kernel", p.co_s / 16, p.ci_s / 16, resample, p.tw);
+    if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
+    else snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw, wgrad_f32_waves(p.co_s / 16, p.ci_s / 16));
     return NGAN_OK;
 }
 
