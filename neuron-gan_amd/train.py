@@ -555,13 +555,15 @@ class TensorImageDataset(torch.utils.data.Dataset):
 
 
 def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_final=None, use_graph=True, log=print,
-                samples_dir=None):
+                samples_dir=None, on_epoch=None):
     """The reference's epoch loop (train.py:298-451) over a PGGANTrainer.
     Per epoch: advance alpha / grow (318-333), one pass over the dataset in batches of cfg.batch_size (350-394), sample-weighted
     epoch means of the monitors (387-398), a status line every 10 epochs (401-422), LR schedule (424-426), loss series (429-432),
     checkpoint + sample grid every cfg.checkpointing_period epochs (435-443).  The monitors stay on the GPU and are read back one
     epoch late through pinned memory, so the host never stalls the launch stream; a NaN loss raises ValueError like the
-    reference's loss modules do (loss_functions.py:35-41, 70-72)."""
+    reference's loss modules do (loss_functions.py:35-41, 70-72).
+    on_epoch(epoch, trainer): optional observer, called once per epoch after the alpha / growth update, i.e. with the structure and
+    the learning rate the epoch trains with (what the reference's status line prints, train.py:401-422)."""
     import time
     from .utils import Calculate_D_steps, similarity_loss
     adapt_period = 100                                                # Disc_adapt_update_period, train.py:190
@@ -605,6 +607,8 @@ def pggan_train(trainer, dataset, cfg, checkpoint=None, epoch_init=1, epoch_fina
     for epoch in range(epoch_init, epoch_final):
         if trainer.start_epoch(epoch, cfg.transit_sch):
             dataset.set_image_size(G.image_size)
+        if on_epoch is not None:
+            on_epoch(epoch, trainer)
         # number of critic steps this epoch (train.py:336-340); the score series lags one epoch here (deferred read-back)
         if adapt_critic and len(series["score_real"]) > adapt_period:
             n_d_steps = Calculate_D_steps(series["score_real"], series["score_fake"], 0, cfg.n_critic, Period=adapt_period)

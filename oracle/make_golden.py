@@ -206,6 +206,11 @@ def full_fixture(models, config, name):
     for k, v in cap.items():
         if k.startswith(("Dgrad/", "Ggrad/", "Ggrad_pre/")):
             out["cs/" + k] = np.array([float(v.astype(np.float64).sum()), float(np.abs(v.astype(np.float64)).sum())])
+            # element-wise pins besides the checksums: the first 96 entries of every gradient tensor, its largest entry and the
+            # tensor's max-norm (the scale the comparison is made on)
+            flat = v.reshape(-1)
+            out["sl/" + k] = flat[:96].copy()
+            out["mx/" + k] = np.array([float(np.argmax(np.abs(flat))), float(flat[np.argmax(np.abs(flat))]), float(np.abs(flat).max())])
     out["scalars"] = np.array([scal[k] for k in ("D_loss", "score_real", "score_fake", "GP", "G_loss")], dtype=np.float64)
     out["G_loss_pre"] = cap["G_loss_pre"]
     for k, v in checksums(G).items():
@@ -288,6 +293,53 @@ def checkpoint_fixtures(models):
     print("checkpoint fixtures written:", new_path, old_path)
 
 
+# ------------------------------------------------------------------------------------------
+# epoch-level fixture: what the reference's epoch loop does to the nets and the learning rate, epoch by epoch.
+# The growth calls are the reference's own (models.py:355-392, 526-564), driven in the order of train.py:318-333; the learning
+# rate follows update_lr (train.py:250-265), which lives in the module-level script train.py (not importable: parse/torchvision,
+# prompts, dataset) and is restated here on a plain dict.
+# ------------------------------------------------------------------------------------------
+def epoch_fixture(models):
+    transit_sch, n_epochs, alpha_step, base_lr = [3, 6], 9, 0.5, 1e-3
+    torch.manual_seed(5)
+    G = models.Generator_PG(list(SMALL["g_widths"]), image_size_init=SMALL["image_size_init"], latent_dim=SMALL["latent_dim"])
+    D = models.Discriminator_PG(list(SMALL["d_widths"]), image_size_init=SMALL["image_size_init"])
+    bounds = [0] + transit_sch + [n_epochs]                                            # train.py:243
+    decay = [np.exp(np.log(1 / 100) / ((bounds[i + 1] - bounds[i]) / 2)) for i in range(len(bounds) - 1)]   # train.py:244-247
+    group = {"lr": base_lr}
+
+    def update_lr(epoch):                                                              # train.py:250-265
+        if epoch in bounds:
+            group["lr"] = base_lr
+        else:
+            phase = sum(epoch > t for t in transit_sch)
+            n = bounds[phase + 1] - bounds[phase]
+            since = epoch - bounds[phase]
+            if since <= n / 2:
+                group["lr"] = base_lr * (decay[phase] ** since)
+
+    update_lr(0)                                                                       # train.py:288-289 (epoch_init - 1)
+    out = {"meta": np.array([n_epochs, alpha_step, base_lr] + transit_sch, dtype=np.float64)}
+    rows, gkeys, dkeys = [], [], []
+    for epoch in range(1, n_epochs + 1):                                               # train.py:312
+        lr = group["lr"]                                                               # train.py:316: the rate this epoch trains with
+        if G.alpha < 1 and D.alpha < 1:                                                # train.py:319-321
+            G.advance_transition(alpha_step)
+            D.advance_transition(alpha_step)
+        if epoch in transit_sch:                                                       # train.py:328-330
+            G.increase_resolution()
+            D.increase_resolution()
+        rows.append([epoch, float(G.alpha), float(D.alpha), G.image_size, D.image_size, G.N_layers, D.N_layers, lr])
+        gkeys.append("|".join(G.state_dict().keys()))
+        dkeys.append("|".join(D.state_dict().keys()))
+        update_lr(epoch)                                                               # train.py:425-426
+    out["rows"] = np.array(rows, dtype=np.float64)
+    out["G_keys"] = np.array(gkeys)
+    out["D_keys"] = np.array(dkeys)
+    np.savez_compressed(os.path.join(OUT, "epochs_small.npz"), **out)
+    print("epochs_small.npz:", out["rows"][:, [0, 1, 3, 7]].tolist())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also regenerate the full-width C3/C4 pins (about a minute of CPU)")
@@ -304,6 +356,8 @@ def main():
             small_fixture(models, name, res, alpha, warm)
     if not only or "checkpoint" in only:
         checkpoint_fixtures(models)
+    if not only or "epochs" in only:
+        epoch_fixture(models)
     for name in (["C1", "C2"] + (["C3", "C4", "C5"] if args.full else [])):
         if not only or name in only:
             full_fixture(models, config, name)

@@ -51,6 +51,18 @@ def run_step_losses(ngan, G, D, fix, lam=10.0, drift=0.001, lr=1e-4):
     return scal, norms, dgrads, ggrads
 
 
+def check_slices(fix, key, g, tol):
+    """element-wise pins of the full-width fixtures: the first 96 entries and the largest entry of a gradient tensor, on the
+    tensor's max-norm (a checksum can hide compensating errors; these cannot)"""
+    if "sl/" + key not in fix:
+        return
+    flat = np.asarray(g, np.float64).reshape(-1)
+    sl, mx = fix["sl/" + key].astype(np.float64), fix["mx/" + key]
+    scale = float(mx[2])
+    assert float(np.abs(flat[:sl.size] - sl).max()) < tol * scale, (key, "slice")
+    assert abs(flat[int(mx[0])] - mx[1]) < tol * scale, (key, "largest entry")
+
+
 def adam_close(got, want, lr):
     """first Adam step moves each weight by ~lr*sign(g): allow a few sign flips where |g| is at rounding level"""
     bad = np.mean(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64)) > 0.1 * lr)
@@ -138,6 +150,9 @@ def test_full_width_pins(ngan, name, conv_precision):
             # differently move it by up to 2.3e-3 in split-bf16 mode while every operator agrees with fp64 to < 1e-5
             # (tools/first_block_sensitivity.py prints the four arithmetic variants); exact-fp32 mode stays below 1.2e-4
             assert abs(got - cs[1]) < (4e-3 if k.startswith("ToIm") else 2e-3) * cs[1], ("G pre", k, got, cs[1])
+            # element-wise: 5e-3 of the tensor's max-norm (init-state generator gradients are ~1e-5 and sums over 2M pixels whose
+            # LeakyReLU ties fall either way; measured worst over C1-C5 in exact fp32: 2.2e-3, layers.8.1.weight of C5)
+            check_slices(fix, "Ggrad_pre/" + k, p.grad.cpu().numpy(), 5e-3)
     G.zero_grad()
     D.zero_grad()
     scal, norms, dgrads, ggrads = run_step_losses(ngan, G, D, fx)
@@ -146,6 +161,11 @@ def test_full_width_pins(ngan, name, conv_precision):
     for k, g in dgrads.items():
         cs = fix["cs/Dgrad/" + k]
         assert abs(float(np.abs(g.astype(np.float64)).sum()) - cs[1]) < 2e-3 * cs[1], ("D", k)
+        # element-wise (tools/pin_report.py prints the worst tensor of every config and mode): exact fp32 stays within 1.7e-3 of the
+        # tensor's max-norm; in split-bf16 mode the bias gradient of the critic's last 3x3 conv reaches 9.8e-3 (its 4e-6 forward
+        # error is amplified by the cancellation in the PixelNorm backward of a nearly radial gradient), everything else 1.4e-3
+        tol = 2e-3 if conv_precision == "f32" else (2e-2 if k.endswith(".bias") else 5e-3)
+        check_slices(fix, "Dgrad/" + k, g, tol)
     # after the critic's first Adam step (each weight moves by ~lr*sign(g), so a rounding-level critic gradient can flip a
     # step): the generator gradients seen through the updated critic scatter by 1e-3 .. 1.1e-2 between arithmetic variants
     # whose critic gradients all agree with the reference to 1e-4 (tools/c2_sensitivity.py prints the four variants: exact
@@ -213,3 +233,59 @@ def test_losses_and_gradients_match_oracle_on_the_fly(ngan, n_colors, res, alpha
         if p.grad is not None:
             ok, info = close(p.grad, pg[k].grad, gmax)
             assert ok, ("G", k, info)
+
+
+@pytest.mark.parametrize("name", ["small_res8_warm", "small_res16_fade_warm", "small_res16_warm"])
+def test_reference_inner_loop_verbatim_over_the_drop_in_modules(ngan, name, conv_precision, monkeypatch):
+    """INTEGRATION.md claims the reference's inner loop runs unchanged over these modules.  This is train.py:357-385 line for line
+    -- zero_grad(), the loss modules called with the images ONLY, `D_loss_val += gp`, backward(), torch.optim.Adam.step() over
+    net.parameters() -- with nothing of the step driver (no PGGANTrainer, no flat buffers, no fused Adam).  The latents and epsilon
+    the loss modules draw are the fixture's, injected where the reference draws them: `sample_latent_vec` (looked up at call time,
+    loss_functions.py:25, 63, 166) and `torch.rand` (loss_functions.py:170)."""
+    fix = load_golden(name)
+    Generator_net, Discriminator_net = build_small(ngan, fix)
+    LF = ngan.loss_functions
+    lr = float(fix["meta"][5])
+    optimizer_gen = torch.optim.Adam(Generator_net.parameters(), lr=lr, betas=(0.5, 0.999))      # train.py:224-225
+    optimizer_dis = torch.optim.Adam(Discriminator_net.parameters(), lr=lr, betas=(0.5, 0.999))
+    G_loss = LF.G_W_loss(Generator_net, Discriminator_net)                                       # train.py:228-230
+    D_loss = LF.D_W_loss(Generator_net, Discriminator_net, drift_epsilon=0.001)
+    D_grad_loss = LF.D_grad_pen_loss(Generator_net, Discriminator_net, Lambda=10.0)
+    draws = iter([fix["z_d"], fix["z_gp"], fix["z_g"]])                                          # call order of one iteration (SURVEY.md 3.2)
+    monkeypatch.setattr(LF, "sample_latent_vec", lambda size, *a, **k: torch.from_numpy(next(draws)).to(DEV))
+    real_rand = torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: torch.from_numpy(fix["eps"]).to(DEV) if tuple(a[0]) == tuple(fix["eps"].shape) else real_rand(*a, **k))
+    images = torch.from_numpy(fix["real"]).to(DEV)                                               # train.py:352-353
+    # ---- train.py:356-385, n_critic = 1, sim_loss off ----
+    Discriminator_net.zero_grad()
+    D_loss_val, score_real, score_fake = D_loss(images)
+    D_grad_pen_loss = D_grad_loss(images)
+    D_loss_val += D_grad_pen_loss
+    D_loss_val.backward()
+    d_grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in Discriminator_net.named_parameters() if p.grad is not None}
+    optimizer_dis.step()
+    Generator_net.zero_grad()
+    G_loss_val, z = G_loss(images)
+    G_loss_val.backward()
+    g_grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in Generator_net.named_parameters() if p.grad is not None}
+    optimizer_gen.step()
+    monkeypatch.undo()
+    # ---- against the reference's numbers ----
+    got = np.array([D_loss_val.item(), score_real.item(), score_fake.item(), D_grad_pen_loss.item(), G_loss_val.item()])
+    assert np.allclose(got, fix["scalars"], rtol=1e-3, atol=2e-5), (got, fix["scalars"])
+    assert rel(D_grad_loss.last_grad_norms.cpu().numpy(), fix["grad_norms"]) < 1e-3
+    assert np.array_equal(z.cpu().numpy(), fix["z_g"])
+    want_d, want_g = split_state(fix, "Dgrad/"), split_state(fix, "Ggrad/")
+    assert set(d_grads) == set(want_d) and set(g_grads) == set(want_g)       # exactly the reference's set of .grad-not-None parameters
+    scale_d = max(float(np.abs(v).max()) for v in want_d.values())
+    for k, v in want_d.items():
+        assert float(np.abs(d_grads[k] - v).max()) < 2e-3 * (float(np.abs(v).max()) + 1e-2 * scale_d), ("D", k)
+    scale_g = max(float(np.abs(v).max()) for v in want_g.values())
+    for k, v in want_g.items():
+        assert float(np.abs(g_grads[k] - v).max()) < 2e-3 * (float(np.abs(v).max()) + 1e-2 * scale_g), ("G", k)
+    for k, v in split_state(fix, "D_after/").items():
+        if v.ndim:
+            assert adam_close(Discriminator_net.state_dict()[k].cpu().numpy(), v, lr), ("D after Adam", k)
+    for k, v in split_state(fix, "G_after/").items():
+        if v.ndim:
+            assert adam_close(Generator_net.state_dict()[k].cpu().numpy(), v, lr), ("G after Adam", k)

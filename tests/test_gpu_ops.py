@@ -537,3 +537,31 @@ def test_persistent_conv_with_many_tiles_per_workgroup(ngan, case, conv_precisio
     assert not torch.isnan(got).any()
     worst = float((got - c).abs().max() / c.abs().max())
     assert worst < 2e-4, worst
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 16, 16, 0), (1, 64, 64, 32, 32, 0), (2, 8, 8, 64, 64, 0), (1, 32, 64, 16, 32, 1), (2, 32, 32, 32, 16, 2)])
+def test_conv_lrelu_pn_with_the_reference_own_leaky_mask(ngan, case, conv_precision):
+    """The other conv tests hand the fp64 reference the kernel's own LeakyReLU sign pattern (`lrelu_like`), so a wrong sign rule in
+    the kernel could hide.  Here the pre-activations are kept away from zero -- a bias of +-8 per output channel on top of a conv
+    result of |c| < ~4 -- so the sign pattern is unambiguous, half the channels take the 0.2 slope, and the reference applies
+    F.leaky_relu by itself.  All orders: forward, first-order gradients, d/dW of |dL/dx|^2."""
+    B, H, W, Cin, Cout, res = case
+    ops = ngan.ops
+    torch.manual_seed(sum(case) + 1)
+    hin, win = (2 * H, 2 * W) if res == 1 else ((H // 2, W // 2) if res == 2 else (H, W))
+    sign = torch.tensor([1.0 if (c // 2) % 2 == 0 else -1.0 for c in range(Cout)])
+    t = {"x": torch.randn(B, Cin, hin, win), "w": torch.randn(Cout, Cin, 3, 3), "b": 8.0 * sign + 0.5 * torch.randn(Cout)}
+    scale = 1.3868 / np.sqrt(9 * Cin)
+
+    def f_hip(d):
+        y, _ = ops.ConvLReLUPN.apply(nhwc(d["x"]), d["w"], d["b"], res, scale, SLOPE)
+        return nchw(y)
+
+    def f_ref(d):
+        c = F.conv2d(resample_ref(d["x"], res) * scale, d["w"], d["b"], padding=1)
+        assert float(c.abs().min()) > 1.0                   # every pre-activation is far from the kink
+        frac_neg = float((c < 0).double().mean())
+        assert 0.3 < frac_neg < 0.7                         # and both slopes are exercised
+        return pn_ref(F.leaky_relu(c, SLOPE))
+
+    run_both(f_hip, f_ref, t, ["w", "b"], x_name="x")

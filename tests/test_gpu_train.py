@@ -158,6 +158,36 @@ def test_penalty_switched_off_draws_no_second_latent_batch(ngan):
     assert series["D_grad_pen"] == [0.0]
 
 
+def test_epoch_driver_follows_the_reference_epoch_by_epoch(ngan):
+    """tests/golden/epochs_small.npz (reference growth calls driven in train.py's order + update_lr): alpha, image size, layer
+    count, learning rate and state_dict key lists of all nine epochs, observed INSIDE pggan_train through its on_epoch hook, graph
+    replay on -- the epoch driver's growth / re-capture / LR logic against the reference, not against itself."""
+    fix = load_golden("epochs_small")
+    n_epochs, alpha_step, base_lr = int(fix["meta"][0]), float(fix["meta"][1]), float(fix["meta"][2])
+    transit = [int(v) for v in fix["meta"][3:]]
+    cfg = types.SimpleNamespace(adapt_critic=False, sim_loss_lambda=0.0, n_critic=1, batch_size=4, transit_sch=transit, N_epochs=n_epochs,
+                                alpha_step=alpha_step, learning_rate=base_lr, checkpointing_period=100, ID="t004")
+    torch.manual_seed(5)
+    G = ngan.models.Generator_PG([32, 16, 16], image_size_init=4, latent_dim=32).to(DEV)
+    D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=4).to(DEV)
+    tr = ngan.train.PGGANTrainer(G, D, learning_rate=base_lr, alpha_step=alpha_step, device_latents=True)
+    lr0 = ngan.train.lr_schedule(0, base_lr, transit, n_epochs)
+    tr.opt_g.set_lr(lr0)
+    tr.opt_d.set_lr(lr0)
+    seen = []
+
+    def on_epoch(epoch, trainer):
+        seen.append(([epoch, G.alpha_value(), D.alpha_value(), G.image_size, D.image_size, G.N_layers, D.N_layers,
+                      trainer.opt_g.param_groups[0]["lr"]], list(G.state_dict().keys()), list(D.state_dict().keys())))
+    data = ngan.train.TensorImageDataset.synthetic(8, 16, device=DEV)
+    series = ngan.train.pggan_train(tr, data, cfg, epoch_final=n_epochs + 1, log=lambda *_: None, on_epoch=on_epoch)
+    assert len(seen) == n_epochs and np.isfinite(series["D_loss"]).all()
+    for (row, gk, dk), want, wg, wd in zip(seen, fix["rows"], fix["G_keys"], fix["D_keys"]):
+        assert np.allclose(row[:7], want[:7], rtol=0, atol=1e-7), (row, want.tolist())
+        assert abs(row[7] - want[7]) <= 1e-12 * want[7], (row[0], row[7], want[7])
+        assert gk == str(wg).split("|") and dk == str(wd).split("|"), row[0]
+
+
 def test_stem_factor_exchange_matches_plain_gradient(ngan):
     """The data-parallel path forms the stem's weight gradient from (gathered) factors after the backward pass; with one rank
     that must give exactly the weights of the plain path."""

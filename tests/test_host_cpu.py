@@ -216,3 +216,35 @@ def test_adaptive_critic_schedule_and_similarity_monitor():
     zm = zm / np.linalg.norm(zm, axis=1, keepdims=True)
     want = 0.7 * ((zm @ zm.T - xm @ xm.T) ** 2).sum() / 30
     assert abs(float(u.similarity_loss(x, z, 0.7)) - want) < 1e-6
+
+
+def test_epoch_schedule_follows_the_reference_epoch_by_epoch(ngan):
+    """tests/golden/epochs_small.npz was written by oracle/make_golden.py driving the REFERENCE's Generator_PG / Discriminator_PG
+    through nine epochs in the order of train.py:312-333 (alpha advance, then growth at the transition epochs) with the learning
+    rate of update_lr (train.py:250-265): alpha of both nets, image size, layer count, state_dict key lists and the rate each epoch
+    trains with.  The product's host logic (PGGANTrainer.start_epoch + lr_schedule, what pggan_train calls) must reproduce every
+    row -- on the CPU: no kernel is involved."""
+    fix = load_golden("epochs_small")
+    n_epochs, alpha_step, base_lr = int(fix["meta"][0]), float(fix["meta"][1]), float(fix["meta"][2])
+    transit = [int(v) for v in fix["meta"][3:]]
+    torch.manual_seed(5)
+    G = ngan.models.Generator_PG([32, 16, 16], image_size_init=4, latent_dim=32)
+    D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=4)
+    tr = ngan.train.PGGANTrainer(G, D, learning_rate=base_lr, alpha_step=alpha_step)
+    lr0 = ngan.train.lr_schedule(0, base_lr, transit, n_epochs)            # train.py:288-289
+    if lr0 is not None:
+        tr.opt_g.set_lr(lr0)
+        tr.opt_d.set_lr(lr0)
+    for row, gk, dk in zip(fix["rows"], fix["G_keys"], fix["D_keys"]):
+        epoch = int(row[0])
+        tr.start_epoch(epoch, transit)
+        got = [epoch, G.alpha_value(), D.alpha_value(), G.image_size, D.image_size, G.N_layers, D.N_layers, tr.opt_g.param_groups[0]["lr"]]
+        assert np.allclose(got[:7], row[:7], rtol=0, atol=1e-7), (got, row.tolist())
+        assert abs(got[7] - row[7]) <= 1e-12 * row[7] + 1e-18, (epoch, got[7], row[7])
+        assert tr.opt_d.param_groups[0]["lr"] == got[7]
+        assert list(G.state_dict().keys()) == str(gk).split("|"), epoch
+        assert list(D.state_dict().keys()) == str(dk).split("|"), epoch
+        lr = ngan.train.lr_schedule(epoch, base_lr, transit, n_epochs)       # train.py:424-426, as pggan_train applies it
+        if lr is not None:
+            tr.opt_g.set_lr(lr)
+            tr.opt_d.set_lr(lr)
