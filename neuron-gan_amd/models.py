@@ -313,6 +313,35 @@ def _plan(mods, steps=None, pending=None):
     return steps
 
 
+def _odd_width(m):
+    return m.weight.shape[0] % 16 != 0 or m.weight.shape[1] % 16 != 0
+
+
+def _conv_any_width(x, m, res, slope):
+    """3x3 conv (+ LeakyReLU -> PixelNorm when `slope` is given) for channel counts that are not multiples of 16 -- the reference's
+    constructors take any widths and its presets 0004-0006 end in 8-channel blocks (configs/config.py:86-92).  The contraction
+    kernels work on multiples of 16, so the weight, bias and input are zero-padded up to the next multiple, the conv runs on the
+    padded shapes, the padding channels are cut off again and LeakyReLU -> PixelNorm runs on the REAL channel count (its mean is
+    over the layer's own channels).  Padding and slicing are torch's differentiable ops, every kernel involved is closed under
+    double-backward, so all gradient orders are exact; it is an unfused compatibility path (no PixelNorm hand-off, no ToImage /
+    first-block fusion), not a fast one."""
+    co, ci = m.weight.shape[0], m.weight.shape[1]
+    if co % 4 or ((co // 4) & (co // 4 - 1)) or co > 256:
+        raise NotImplementedError(f'PixelNorm kernels take 4, 8, 16, ... 256 channels, got {co}')
+    cip, cop = -(-ci // 16) * 16, -(-co // 16) * 16
+    w = torch.nn.functional.pad(m.weight, (0, 0, 0, 0, 0, cip - ci, 0, cop - co))
+    b = torch.nn.functional.pad(m.bias, (0, cop - co)) if m.bias is not None else None
+    if x.shape[-1] != cip:
+        x = torch.nn.functional.pad(x, (0, cip - x.shape[-1]))
+    c = ops.Conv.apply(x.contiguous(), w, b, res, m.scale_value)
+    if cop != co:
+        c = c[..., :co].contiguous()
+    if slope is None:
+        return c
+    y, _ = ops.LReLUPN.apply(c, None, slope)
+    return y
+
+
 def _exec(steps, x, link=None, to_image=None):
     """Run planned steps on a channels-last tensor (or on latents for the stem).  `link`: PNLink of the LeakyReLU->PixelNorm that
     produced x, if x has no other consumer.  Returns (output, link of the output).  Inside `ops.first_order_only()` consecutive
@@ -322,7 +351,11 @@ def _exec(steps, x, link=None, to_image=None):
     last = len(steps) - 1
     for idx, st in enumerate(steps):
         kind = st[0]
-        if kind == 'conv_lrelu_pn':
+        if kind == 'conv_lrelu_pn' and _odd_width(st[1]):
+            x, link = _conv_any_width(x, st[1], st[2], st[3]), None
+        elif kind == 'conv' and st[1].is_3x3() and _odd_width(st[1]):
+            x, link = _conv_any_width(x, st[1], st[2], None), None
+        elif kind == 'conv_lrelu_pn':
             _, m, res, slope = st
             if (idx == last and to_image is not None and ops.first_order_enabled()
                     and ops.to_image_fusable(x, m.weight, to_image.layers[0].weight, res)):

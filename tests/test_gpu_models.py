@@ -176,14 +176,17 @@ def test_full_width_pins(ngan, name, conv_precision):
         assert abs(float(np.abs(g.astype(np.float64)).sum()) - cs[1]) < 2e-2 * cs[1], ("G", k)
 
 
-@pytest.mark.parametrize("n_colors,res,alpha", [(3, 16, 0.5), (3, 16, 1.0), (1, 32, 1.0)])
-def test_losses_and_gradients_match_oracle_on_the_fly(ngan, n_colors, res, alpha, conv_precision):
+@pytest.mark.parametrize("n_colors,res,alpha,widths", [(3, 16, 0.5, None), (3, 16, 1.0, None), (1, 32, 1.0, None),
+                                                       # widths that are not multiples of 16: the reference's presets 0004-0006 end in
+                                                       # 8-channel blocks (configs/config.py:86-92); zero-padded contraction path
+                                                       (1, 16, 0.5, ([32, 8], [8, 32])), (1, 32, 1.0, ([16, 8, 8], [8, 8, 16]))])
+def test_losses_and_gradients_match_oracle_on_the_fly(ngan, n_colors, res, alpha, widths, conv_precision):
     """Configurations the committed fixtures do not hold (RGB images: the reference's N_colors constructor argument; a 32x32 stable
     stage of a three-block net): one critic loss + gradient penalty + generator loss against the CPU oracle evaluated here on the
     same weights and draws.  The oracle itself is pinned by tests/test_oracle_golden.py."""
     from oracle import pggan_oracle as O
     torch.manual_seed(11 + n_colors + res)
-    gw, dw = ([32, 16], [16, 32]) if res == 16 else ([32, 16, 16], [16, 16, 32])
+    gw, dw = widths if widths is not None else (([32, 16], [16, 32]) if res == 16 else ([32, 16, 16], [16, 16, 32]))
     G = ngan.models.Generator_PG(gw, image_size_init=8, latent_dim=64, N_colors=n_colors)
     D = ngan.models.Discriminator_PG(dw, image_size_init=8, N_colors=n_colors)
     G.set_resolution(res, alpha)
