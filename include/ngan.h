@@ -121,7 +121,7 @@ int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspa
  *   { const float* partial[4]; float* gw; int nparts[4]; int nsrc, nslices, n_ci_slices, co_s, ci_s, K, accumulate, reserved;
  *     float scale[4]; }                                                                                     (104 bytes)
  * with (nparts, nslices, n_ci_slices, co_s, ci_s) from ngan_conv3x3_wgrad_plan (out5).  accumulate != 0: gw += sum. */
-int ngan_conv3x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int* out5);
+int ngan_conv3x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int precision, int* out5);
 int ngan_conv3x3_wgrad_reduce_many(const void* entries, int n, void* stream);
 
 /* ---- LeakyReLU -> PixelNorm: models.py:263-264, 118-126 (ATen leaky_relu, pow, mean, sqrt, div) ---------------

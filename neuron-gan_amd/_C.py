@@ -71,7 +71,7 @@ NON_STATUS = {
     "ngan_conv3x3_epilogue_fused": ([_I, _I, _I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_packed_floats": ([_I, _I, _I], _L),
     "ngan_conv3x3_pack_elements": ([_I, _I, _I, _I], _L),
-    "ngan_conv3x3_wgrad_plan": ([_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int)], _I),
+    "ngan_conv3x3_wgrad_plan": ([_I, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int)], _I),
 }
 
 _lib = None
@@ -178,9 +178,9 @@ def conv3x3_packed_floats(cout, cin, precision) -> int:
     return int(lib().ngan_conv3x3_packed_floats(cout, cin, precision))
 
 
-def wgrad_plan(B, H, W, Cin, Cout):
+def wgrad_plan(B, H, W, Cin, Cout, precision=0):
     out = (ctypes.c_int * 5)()
-    if lib().ngan_conv3x3_wgrad_plan(B, H, W, Cin, Cout, out) != 0:
+    if lib().ngan_conv3x3_wgrad_plan(B, H, W, Cin, Cout, precision, out) != 0:
         raise RuntimeError(lib().ngan_last_error().decode())
     return tuple(out)
 

@@ -2139,7 +2139,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 struct WgradPlan { int co_s, ci_s, nslices, n_ci_slices, tiles_x, tiles_y, n_tiles, nwx, tw; };
 constexpr int wgrad_f32_waves(int cot, int cit) { return cot * cit == 4 ? 8 : 4; }    // a 32 x 32 slice: two waves per 16 x 16 sub-slice
 
-WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
+WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout, int precision = 1) {
     WgradPlan p;
     p.co_s = (Cout % 32 == 0) ? 32 : 16;
     p.ci_s = (Cin % 32 == 0) ? 32 : 16;
@@ -2149,8 +2149,12 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
     p.tiles_x = ngan::ceil_div(W, p.tw);
     p.tiles_y = ngan::ceil_div(H, 256 / p.tw);
     p.n_tiles = B * p.tiles_x * p.tiles_y;
-    static const int total = [] { const char* e = getenv("NGAN_WGRAD_SLABS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 512; }();   // (A/B switch)
-    int cap = total / p.nslices;   // about two resident workgroups per CU: few slabs to reduce afterwards (256 / 768 measured slower)
+    static const int forced = [] { const char* e = getenv("NGAN_WGRAD_SLABS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 0; }();   // (A/B switch)
+    // about two resident workgroups per CU: few slabs to reduce afterwards (256 / 768 measured slower).  The fp32 kernel's 32 x 32
+    // slices are 8-wave workgroups with 83 KB of LDS, one per CU: 256 of them (fp32 32 -> 32 at 128x128: 100 vs 106 us, 64 -> 64 at
+    // 32x32: 33 vs 39 us)
+    const int total = forced ? forced : ((precision == 0 && p.co_s == 32 && p.ci_s == 32) ? 256 : 512);
+    int cap = total / p.nslices;
     if (cap < 1) cap = 1;
     p.nwx = p.n_tiles < cap ? p.n_tiles : cap;
     return p;
@@ -2439,7 +2443,7 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
     NGAN_REQUIRE(buf && len > 0, NGAN_ERR_ARG, "conv3x3_wgrad_kernel_name: bad buffer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_wgrad_kernel_name: bad shape");
-    const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
+    const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
     if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
     else snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw, wgrad_f32_waves(p.co_s / 16, p.ci_s / 16));
     return NGAN_OK;
@@ -2521,10 +2525,10 @@ extern "C" size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci
     return (size_t)p.nwx * p.nslices * 9 * p.co_s * p.ci_s * sizeof(float);
 }
 
-extern "C" int ngan_conv3x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int* out5) {
+extern "C" int ngan_conv3x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int precision, int* out5) {
     NGAN_REQUIRE(out5 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_ARG,
                  "conv3x3_wgrad_plan: bad argument");
-    WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
+    WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
     out5[0] = p.nwx; out5[1] = p.nslices; out5[2] = p.n_ci_slices; out5[3] = p.co_s; out5[4] = p.ci_s;
     return NGAN_OK;
 }
@@ -2562,7 +2566,7 @@ extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, flo
     NGAN_REQUIRE(resample >= 0 && resample <= 2, NGAN_ERR_ARG, "conv3x3_wgrad: resample %d", resample);
     NGAN_REQUIRE(resample != NGAN_RESAMPLE_UP2 || (H % 2 == 0 && W % 2 == 0), NGAN_ERR_SHAPE,
                  "conv3x3_wgrad: bilinear x2 needs even H, W");
-    WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
+    WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
     WgradArgs a{x, g, workspace, B, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.n_tiles, p.n_ci_slices};
     hipStream_t s = (hipStream_t)stream;
     int st;

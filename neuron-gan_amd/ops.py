@@ -305,7 +305,7 @@ def _run_wgrad(x, g, resample, scale, accumulate_into=None, role=0):
     ws = torch.empty(_C.wgrad_workspace_bytes(b, h, w, cin, cout) // 4, device=g.device, dtype=torch.float32)
     if accumulate_into is not None and _defer_depth > 0:
         _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 2, _conv_precision)
-        plan = _C.wgrad_plan(b, h, w, cin, cout)
+        plan = _C.wgrad_plan(b, h, w, cin, cout, _conv_precision)
         e = _pending.setdefault(gw.data_ptr(), dict(gw=gw, plan=plan, cin=cin, sources=[]))
         e["sources"].append((ws, plan[0], float(scale), role))
         return gw

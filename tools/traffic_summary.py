@@ -31,7 +31,7 @@ for name in sorted(set(fetch) | set(write)):
     wr = w * 1024.0 / max(nw, 1)
     kernels[name] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-                      "--no-cpu-baseline --no-probe --graph 0",
+                      "--no-cpu-baseline --no-probe --graph 0 --sub-record 0 --precision <mode> (tools/measure_round.sh)",
            "correction": "FETCH_SIZE x2 (gfx950 reports half of a wide streaming read), KiB -> bytes", "kernels": kernels},
           open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(kernels), "kernels")
