@@ -191,6 +191,22 @@ int ngan_xhat(const float* real, const float* fake, const float* eps, float* out
  * norms[b] = ||g[b,:]||_2 (two fixed-order stages; rows 16-byte aligned, n a multiple of 4);   scale_rows: out[b,:] = coef[b] * g[b,:] */
 int ngan_sample_l2norm(const float* g, float* norms, float* workspace /* 64*B floats */, int B, long n, void* stream);
 int ngan_scale_rows(const float* g, const float* coef, float* out, int B, long n, void* stream);
+/* the penalty's scalar head and its adjoint: out1 = lambda * mean((norms - 1)^2);  coef[b] = g_out * 2 lambda (norms[b] - 1) / (B norms[b])
+ * (feed coef to ngan_scale_rows to get the gradient w.r.t. g) */
+int ngan_gp_head(const float* norms, int B, float lambda, float* out1, void* stream);
+int ngan_gp_coef(const float* norms, int B, float lambda, const float* g_out /* 1 float */, float* coef, void* stream);
+
+/* ---- scalar heads of the Wasserstein losses: loss_functions.py:21-45, 67 (ATen mean / neg / add / square chains) -----------
+ * scores holds n_real real scores followed by n_fake fake scores.  loss = -mean(real) + mean(fake) + drift * mean(real^2), plus the two means
+ * (three separate 1-float outputs);  n_fake = 0 gives -mean(scores), the generator loss.  bwd: gradient w.r.t. scores from the three
+ * output gradients (device scalars, NULL = 0). */
+int ngan_wloss_head(const float* scores, int n_real, int n_fake, float drift, float* loss, float* mean_real, float* mean_fake,
+                    void* stream);
+int ngan_wloss_head_bwd(const float* scores, int n_real, int n_fake, float drift, const float* g_loss, const float* g_real,
+                        const float* g_fake, float* g_scores, void* stream);
+
+/* ---- latent projection: utils.py:77-78 (clamp(-c, c), L2-normalise each row), in place on (rows, dim) normal draws ---------- */
+int ngan_latent_normalize(float* z, int rows, int dim, float clamp, void* stream);
 
 /* ---- generator stem: Linear_normalized -> Unflatten -> LeakyReLU -> PixelNorm, models.py:299-311 (ATen mm) --------
  * fwd:   y[b][p][c] = PN(LReLU(scale * sum_k z[b][k] * Wt[c*S + p][k])),  y (B,S,C), rnorm (B,S); W is (C*S, K)

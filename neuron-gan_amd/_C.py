@@ -42,6 +42,11 @@ SIGNATURES = {
     "ngan_xhat": [_P, _P, _P, _P, _I, _L, _P],
     "ngan_sample_l2norm": [_P, _P, _P, _I, _L, _P],
     "ngan_scale_rows": [_P, _P, _P, _I, _L, _P],
+    "ngan_gp_head": [_P, _I, _F, _P, _P],
+    "ngan_gp_coef": [_P, _I, _F, _P, _P, _P],
+    "ngan_wloss_head": [_P, _I, _I, _F, _P, _P, _P, _P],
+    "ngan_wloss_head_bwd": [_P, _I, _I, _F, _P, _P, _P, _P, _P],
+    "ngan_latent_normalize": [_P, _I, _I, _F, _P],
     "ngan_linear_lrelu_pn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P],
     "ngan_linear_wgrad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ngan_linear_wgrad_acc": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],

@@ -43,6 +43,7 @@ int reduce_partials(const float* partials, int nparts, int M, float* out, float 
     return reduce_partials_strided(partials, nparts, M, M, out, scale, s);
 }
 
+
 }  // namespace ngan
 
 namespace {
@@ -524,7 +525,108 @@ int ew_blocks(long n) {
         default: CALL(64); break;              \
     }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Scalar heads of the losses and the latent projection: each replaces a chain of 4 - 10 ATen elementwise / reduction launches
+// of a few microseconds (88 such launches were 5 % of an exact-fp32 iteration, 7 % of a split-bf16 one).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = group_sum<64>(v);
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// z[r, :] = clamp(z[r, :], -c, c) / ||clamp(z[r, :], -c, c)||_2   (reference utils.py:77-78), in place; one wave per row
+__global__ __launch_bounds__(64) void latent_normalize_kernel(float* __restrict__ z, int dim, float c) {
+    float* row = z + (long)blockIdx.x * dim;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < dim; i += 64) {
+        const float v = fminf(fmaxf(row[i], -c), c);
+        ss += v * v;
+    }
+    ss = group_sum<64>(ss);
+    const float inv = 1.0f / sqrtf(ss);
+    for (int i = threadIdx.x; i < dim; i += 64) row[i] = fminf(fmaxf(row[i], -c), c) * inv;
+}
+
+// out = {loss, mean real score, mean fake score}; loss = -mean(real) + mean(fake) + drift * mean(real^2)  (loss_functions.py:21-45;
+// with n_fake = 0: -mean(real), the generator loss, loss_functions.py:67)
+__global__ __launch_bounds__(256) void wloss_head_kernel(const float* __restrict__ scores, int n_real, int n_fake, float drift,
+                                                         float* __restrict__ o_loss, float* __restrict__ o_real, float* __restrict__ o_fake) {
+    __shared__ float red[4];
+    float sr = 0.f, sq = 0.f, sf = 0.f;
+    for (int i = threadIdx.x; i < n_real; i += 256) { const float v = scores[i]; sr += v; sq += v * v; }
+    for (int i = threadIdx.x; i < n_fake; i += 256) sf += scores[n_real + i];
+    sr = block_sum_256(sr, red); sq = block_sum_256(sq, red); sf = block_sum_256(sf, red);
+    if (threadIdx.x == 0) {
+        const float mr = sr / (float)n_real, mf = n_fake ? sf / (float)n_fake : 0.f;
+        o_loss[0] = -mr + mf + (drift > 0.f ? drift * sq / (float)n_real : 0.f);
+        o_real[0] = mr; o_fake[0] = mf;
+    }
+}
+
+__global__ __launch_bounds__(256) void wloss_head_bwd_kernel(const float* __restrict__ scores, int n_real, int n_fake, float drift,
+                                                             const float* __restrict__ g_loss, const float* __restrict__ g_real,
+                                                             const float* __restrict__ g_fake, float* __restrict__ gs) {
+    const float gl = g_loss ? g_loss[0] : 0.f, gr = g_real ? g_real[0] : 0.f, gf = g_fake ? g_fake[0] : 0.f;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_real) gs[i] = (gl * (-1.0f + 2.0f * drift * scores[i]) + gr) / (float)n_real;
+    else if (i < n_real + n_fake) gs[i] = (gl + gf) / (float)n_fake;
+}
+
+// penalty = lambda * mean((norms - 1)^2)  (loss_functions.py:176);  coef[b] = g_out * 2 lambda (norms[b] - 1) / (B norms[b])
+__global__ __launch_bounds__(256) void gp_head_kernel(const float* __restrict__ norms, int B, float lambda, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) { const float d = norms[i] - 1.0f; s += d * d; }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = lambda * s / (float)B;
+}
+
+__global__ __launch_bounds__(256) void gp_coef_kernel(const float* __restrict__ norms, int B, float lambda, const float* __restrict__ g_out,
+                                                      float* __restrict__ coef) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B) coef[i] = g_out[0] * 2.0f * lambda * (norms[i] - 1.0f) / ((float)B * norms[i]);
+}
+
 }  // namespace
+
+extern "C" int ngan_latent_normalize(float* z, int rows, int dim, float clamp, void* stream) {
+    NGAN_REQUIRE(z && rows > 0 && dim > 0 && clamp > 0.f, NGAN_ERR_ARG, "latent_normalize: bad argument");
+    hipLaunchKernelGGL(latent_normalize_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, z, dim, clamp);
+    return ngan::launch_status("ngan_latent_normalize");
+}
+
+extern "C" int ngan_wloss_head(const float* scores, int n_real, int n_fake, float drift, float* loss, float* mean_real, float* mean_fake,
+                               void* stream) {
+    NGAN_REQUIRE(scores && loss && mean_real && mean_fake && n_real > 0 && n_fake >= 0, NGAN_ERR_ARG, "wloss_head: bad argument");
+    hipLaunchKernelGGL(wloss_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, n_real, n_fake, drift, loss, mean_real, mean_fake);
+    return ngan::launch_status("ngan_wloss_head");
+}
+
+extern "C" int ngan_wloss_head_bwd(const float* scores, int n_real, int n_fake, float drift, const float* g_loss, const float* g_real,
+                                   const float* g_fake, float* g_scores, void* stream) {
+    NGAN_REQUIRE(scores && g_scores && n_real > 0 && n_fake >= 0, NGAN_ERR_ARG, "wloss_head_bwd: bad argument");
+    hipLaunchKernelGGL(wloss_head_bwd_kernel, dim3(ngan::ceil_div(n_real + n_fake, 256)), dim3(256), 0, (hipStream_t)stream, scores, n_real,
+                       n_fake, drift, g_loss, g_real, g_fake, g_scores);
+    return ngan::launch_status("ngan_wloss_head_bwd");
+}
+
+extern "C" int ngan_gp_head(const float* norms, int B, float lambda, float* out1, void* stream) {
+    NGAN_REQUIRE(norms && out1 && B > 0, NGAN_ERR_ARG, "gp_head: bad argument");
+    hipLaunchKernelGGL(gp_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, norms, B, lambda, out1);
+    return ngan::launch_status("ngan_gp_head");
+}
+
+extern "C" int ngan_gp_coef(const float* norms, int B, float lambda, const float* g_out, float* coef, void* stream) {
+    NGAN_REQUIRE(norms && g_out && coef && B > 0, NGAN_ERR_ARG, "gp_coef: bad argument");
+    hipLaunchKernelGGL(gp_coef_kernel, dim3(ngan::ceil_div(B, 256)), dim3(256), 0, (hipStream_t)stream, norms, B, lambda, g_out, coef);
+    return ngan::launch_status("ngan_gp_coef");
+}
+
 
 extern "C" int ngan_channel_sum(const float* g, float* out, float* workspace, long npix, int C, float scale, void* stream) {
     NGAN_REQUIRE(g && out && workspace, NGAN_ERR_ARG, "channel_sum: null pointer");

@@ -40,17 +40,13 @@ class D_W_loss(nn.Module):
         # concatenated batch (the reference makes two calls, loss_functions.py:21, 29; per-sample results are identical)
         with ops.first_order_only():      # differentiated once (train.py:365): fused PixelNorm-backward epilogues apply
             scores = self.discriminator_net(torch.cat([real_images, fake_images], dim=0))
-        real_images_score = scores[:batch_size]
-        score_real = real_images_score.mean()
-        score_fake = scores[batch_size:].mean()
-        D_loss = -score_real + score_fake
+        # -mean(real) + mean(fake) + drift * mean(real^2) (loss_functions.py:22, 29, 33, 45) as one launch each way
+        D_loss, score_real, score_fake = ops.WLossHead.apply(scores, batch_size, float(self.drift_epsilon) if self.drift_epsilon > 0 else 0.0)
         if self.check_nan:
             if torch.isnan(score_real):
                 raise ValueError('Real loss is nan.')
             if torch.isnan(score_fake):
                 raise ValueError('Fake loss is nan.')
-        if self.drift_epsilon > 0:
-            D_loss = D_loss + self.drift_epsilon * torch.square(real_images_score).mean()
         return D_loss, score_real, score_fake
 
 
@@ -66,7 +62,7 @@ class G_W_loss(nn.Module):
         z_latent = _latents(self.generator_net, batch_size, device, z)
         fake_images = self.generator_net(z_latent)
         with ops.first_order_only():      # differentiated once (train.py:384)
-            G_loss = -self.discriminator_net(fake_images).mean()
+            G_loss = ops.WLossHead.apply(self.discriminator_net(fake_images), batch_size, 0.0)[0]       # -mean(D(G(z)))
         if self.check_nan and torch.isnan(G_loss):
             raise ValueError('Generator loss is nan.')
         return G_loss, z_latent
@@ -79,6 +75,12 @@ class D_grad_pen_loss(nn.Module):
         self.discriminator_net = discriminator_net
         self.Lambda = Lambda
         self.last_grad_norms = None  # per-sample |grad D| of the last call (monitoring / parity tests)
+        self._ones_cache = None
+
+    def _ones(self, like):
+        if self._ones_cache is None or self._ones_cache.shape != like.shape or self._ones_cache.device != like.device:
+            self._ones_cache = torch.ones_like(like)
+        return self._ones_cache
 
     def forward(self, real_images, z=None, epsilon=None, x_tilde=None):
         if not self.Lambda > 0:
@@ -95,7 +97,8 @@ class D_grad_pen_loss(nn.Module):
         x_hat = ops.xhat(real_images, x_tilde, epsilon)
         x_hat.requires_grad_()
         output = self.discriminator_net(x_hat)
-        Disc_grad = torch.autograd.grad(outputs=output.sum(), inputs=x_hat, create_graph=True)[0]
-        norms = ops.SampleL2Norm.apply(Disc_grad)
+        # d(sum of the scores)/d(x_hat) (loss_functions.py:175): grad_outputs = ones instead of a sum node
+        Disc_grad = torch.autograd.grad(outputs=output, inputs=x_hat, grad_outputs=self._ones(output), create_graph=True)[0]
+        penalty, norms = ops.GradPenaltyHead.apply(Disc_grad, float(self.Lambda))
         self.last_grad_norms = norms.detach()
-        return self.Lambda * torch.mean((norms - 1) ** 2)
+        return penalty

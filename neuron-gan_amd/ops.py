@@ -1046,3 +1046,71 @@ class SampleL2Norm(Function):
         out = torch.empty_like(g)
         _C.call("ngan_scale_rows", g, coef, out, b, g.numel() // b)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# scalar heads of the losses (first order: the loss values are differentiated once, train.py:365, 384)
+# ---------------------------------------------------------------------------------------------------------
+class WLossHead(Function):
+    """(loss, mean real score, mean fake score) of scores = [n_real real | n_fake fake]:
+    loss = -mean(real) + mean(fake) + drift * mean(real^2)  (loss_functions.py:21-45); n_fake = 0: -mean(scores), the generator
+    loss (loss_functions.py:67).  One launch forward, one backward, instead of ~8 ATen launches each way."""
+
+    @staticmethod
+    def forward(ctx, scores, n_real, drift):
+        ctx.set_materialize_grads(False)          # (the two means usually carry no gradient: no zero-filled stand-ins)
+        scores = _c(scores)
+        n = scores.numel()
+        # three separate 0-dim tensors, not views of one buffer: the reference's loop modifies the loss in place (`D_loss_val += gp`)
+        loss, s_real, s_fake = (torch.empty((), device=scores.device, dtype=torch.float32) for _ in range(3))
+        _C.call("ngan_wloss_head", scores, int(n_real), int(n - n_real), float(drift), loss, s_real, s_fake)
+        ctx.save_for_backward(scores)
+        ctx.cfg = (int(n_real), int(n - n_real), float(drift))
+        return loss, s_real, s_fake
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl, gr, gf):
+        (scores,) = ctx.saved_tensors
+        n_real, n_fake, drift = ctx.cfg
+        if gl is None and gr is None and gf is None:
+            return None, None, None
+        gs = torch.empty_like(scores)
+        _C.call("ngan_wloss_head_bwd", scores, n_real, n_fake, drift, _c(gl), _c(gr), _c(gf), gs)
+        return gs, None, None
+
+
+class GradPenaltyHead(Function):
+    """(Lambda * mean_b((||g_b||_2 - 1)^2), norms) of the critic's input gradient g (loss_functions.py:176): SampleL2Norm and the
+    penalty arithmetic as one operator; its backward scales g's rows by 2 Lambda (n_b - 1) / (B n_b)."""
+
+    @staticmethod
+    def forward(ctx, g, lam):
+        g = _c(g)
+        b = g.shape[0]
+        norms = torch.empty(b, device=g.device, dtype=torch.float32)
+        ws = torch.empty(64 * b, device=g.device, dtype=torch.float32)
+        _C.call("ngan_sample_l2norm", g, norms, ws, b, g.numel() // b)
+        out = torch.empty((), device=g.device, dtype=torch.float32)
+        _C.call("ngan_gp_head", norms, b, float(lam), out)
+        ctx.save_for_backward(g, norms)
+        ctx.lam = float(lam)
+        ctx.mark_non_differentiable(norms)
+        return out, norms
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gp, _gn):
+        g, norms = ctx.saved_tensors
+        b = g.shape[0]
+        coef = torch.empty(b, device=g.device, dtype=torch.float32)
+        _C.call("ngan_gp_coef", norms, b, ctx.lam, _c(gp), coef)
+        out = torch.empty_like(g)
+        _C.call("ngan_scale_rows", g, coef, out, b, g.numel() // b)
+        return out, None
+
+
+def latent_normalize_(z, clamp=5.0):
+    """in place: rows of normal draws -> clamp(-5, 5) -> unit L2 norm (reference utils.py:77-78); one launch"""
+    _C.call("ngan_latent_normalize", z, z.shape[0], z.shape[1], float(clamp))
+    return z

@@ -317,8 +317,12 @@ class PGGANTrainer:
         # switched off (Lambda = 0, the reference CLI's default) the reference draws no second latent batch, and neither does this
         with_gp = self.gp_loss.Lambda > 0
         with torch.no_grad():
-            zs = [self._latent(b, z_d)] + ([self._latent(b, z_gp)] if with_gp else [])
-            fakes = self.G(torch.cat(zs, dim=0) if with_gp else zs[0])
+            if z_d is None and z_gp is None and self.device_latents:
+                zz = self._latent((2 if with_gp else 1) * b, None)      # both latent batches in one draw: no concatenation
+            else:
+                zs = [self._latent(b, z_d)] + ([self._latent(b, z_gp)] if with_gp else [])
+                zz = torch.cat(zs, dim=0) if with_gp else zs[0]
+            fakes = self.G(zz)
         loss, s_real, s_fake = self.d_loss(real, fake_images=fakes[:b])  # train.py:358
         gp = self.gp_loss(real, x_tilde=fakes[b:] if with_gp else None, epsilon=eps)  # train.py:361
         # train.py:362, 365: D_loss += gp; D_loss.backward().  The two terms share no graph node (separate critic passes), so the sum's

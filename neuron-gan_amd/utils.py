@@ -34,8 +34,9 @@ def sample_latent_vec(size: tuple, seed=None, mode='randn', device=torch.device(
 def sample_latent_vec_device(size: tuple, device, generator=None):
     """Same distribution drawn directly on the GPU (graph-capturable): used by the benchmark / fast training loop,
     where reproducing the CPU RNG stream is not required."""
-    z = torch.randn(*size, device=device, generator=generator).clamp_(-5, 5)
-    return z / z.norm(p=2, dim=1, keepdim=True)
+    from . import ops
+    z = torch.randn(*size, device=device, generator=generator)
+    return ops.latent_normalize_(z, 5.0)          # clamp(-5, 5) and the projection on the unit sphere in one launch
 
 
 # ---------------------------------------------------------------------------------------------------------------------

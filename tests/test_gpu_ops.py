@@ -565,3 +565,41 @@ def test_conv_lrelu_pn_with_the_reference_own_leaky_mask(ngan, case, conv_precis
         return pn_ref(F.leaky_relu(c, SLOPE))
 
     run_both(f_hip, f_ref, t, ["w", "b"], x_name="x")
+
+
+def test_loss_heads_and_latent_projection_match_torch(ngan):
+    """The fused scalar heads (ops.WLossHead, ops.GradPenaltyHead) and the latent projection against the torch expressions of
+    the reference (loss_functions.py:21-45, 67, 176; utils.py:77-78): values and gradients in fp64 on the CPU."""
+    ops = ngan.ops
+    torch.manual_seed(4)
+    b = 24
+    scores = torch.randn(2 * b, 1)
+    # critic head with drift, and the generator head (n_fake = 0)
+    for n_real, drift in ((b, 0.001), (b, 0.0), (2 * b, 0.0)):
+        sr = scores.double().clone().requires_grad_()
+        real, fake = sr[:n_real], sr[n_real:]
+        want = -real.mean() + (fake.mean() if n_real < 2 * b else 0.0) + drift * torch.square(real).mean()
+        sh = scores.to(DEV).clone().requires_grad_()
+        loss, m_real, m_fake = ops.WLossHead.apply(sh, n_real, drift)
+        assert abs(float(loss) - float(want)) < 1e-6 and abs(float(m_real) - float(real.mean())) < 1e-6
+        if n_real < 2 * b:
+            assert abs(float(m_fake) - float(fake.mean())) < 1e-6
+        loss += 0.0                                       # the reference's loop modifies the loss in place: must be allowed
+        (3.0 * loss + 0.5 * m_real).backward()
+        (3.0 * want + 0.5 * real.mean()).backward()
+        assert rel(sh.grad, sr.grad) < 1e-6
+    # gradient-penalty head
+    g = torch.randn(6, 12, 12, 1)
+    gr = g.double().clone().requires_grad_()
+    want = 10.0 * torch.mean((gr.norm(2, dim=(1, 2, 3)) - 1) ** 2)
+    gh = g.to(DEV).clone().requires_grad_()
+    pen, norms = ops.GradPenaltyHead.apply(gh, 10.0)
+    assert rel(norms, gr.norm(2, dim=(1, 2, 3))) < 1e-6 and abs(float(pen) - float(want)) < 1e-5 * float(want)
+    (2.0 * pen).backward()
+    (2.0 * want).backward()
+    assert rel(gh.grad, gr.grad) < 1e-5
+    # latent projection
+    z = torch.randn(7, 512) * 3.0
+    got = ops.latent_normalize_(z.to(DEV).clone(), 5.0).cpu()
+    zc = z.clamp(-5, 5)
+    assert rel(got, zc / zc.norm(p=2, dim=1, keepdim=True)) < 1e-6
