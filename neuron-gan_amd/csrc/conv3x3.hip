@@ -1741,7 +1741,7 @@ __global__ __launch_bounds__(256, (COT * CIT == 1) ? 4 : 2) void wgrad_kernel(Wg
 // ---------------------------------------------------------------------------------------------------------
 constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }      // smallest m >= n with m = 4 (mod 64)
 
-template <int COT, int CIT, int RES, int TW, int NW>
+template <int COT, int CIT, int RES, int TW, int NW, int XF>
 __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
     constexpr int NT = NW * 64;
     constexpr int TH = 256 / TW, HALO_H = TH + 2, NBLK = TW / 16;
@@ -1754,6 +1754,11 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
     constexpr int SMEM = (G_ELEMS + X_ELEMS) > RED_ELEMS ? (G_ELEMS + X_ELEMS) : RED_ELEMS;
     constexpr int NG = TH * TW * (CO_S / 4) / NT, NXI = HALO_H * (TW + 2) * (CI_S / 4), NX = (NXI + NT - 1) / NT;
     static_assert(TH * TW * (CO_S / 4) % NT == 0 && TH % WR == 0 && NW % WO == 0, "tile split");
+    // XF: plain input on an image whose width is a multiple of the 32-pixel tile -- the x tile is staged like conv3x3_tile_kernel's
+    // (interior columns by whole loads at constant per-lane offsets, the descriptor base moved per tile, the top halo row behind a
+    // zero-record descriptor, the two halo columns in one extra load): ~50 fewer VALU instructions per wave and tile
+    constexpr int Q = CI_S / 4, NXINT = HALO_H * 32 * Q / NT, NXF = NXINT + 1, N_HALO = 2 * HALO_H * Q;
+    static_assert(!XF || (RES == NGAN_RESAMPLE_NONE && TW == 32 && (HALO_H * 32 * Q) % NT == 0 && N_HALO <= NT), "fast x staging");
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* g_lds = smem;
     float* x_lds = smem + G_ELEMS;
@@ -1783,12 +1788,28 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
         x_l[i] = (c4 * 4) * PLANE_X + r * XP + c;
     }
     const int x_ch = ci0 + (tid % (CI_S / 4)) * 4;   // (NT is a multiple of CI_S / 4: the channel quad of a thread is the same in every slot)
+    unsigned xf_voff[XF ? NXF : 1];
+    int xf_l[XF ? NXF : 1], xf_bits = 8;
+    if (XF) {
+#pragma unroll
+        for (int i = 0; i < NXINT; ++i) {
+            const int e = tid + i * NT, c4 = e % Q, pix = e / Q, r = pix >> 5, c = (pix & 31) + 1;
+            xf_voff[i] = (unsigned)(((r * a.W + c) * a.K + ci0 + c4 * 4) * 4);
+            xf_l[i] = (c4 * 4) * PLANE_X + r * XP + c;
+        }
+        const int c4 = tid % Q, r = (tid / Q) % HALO_H, side = tid / (Q * HALO_H);
+        const bool used = tid < N_HALO;
+        const int c = side ? 33 : 0;
+        xf_voff[NXINT] = used ? (unsigned)(((r * a.W + c) * a.K + ci0 + c4 * 4) * 4) : 0xFFFFFFF0u;
+        xf_l[NXINT] = (c4 * 4) * PLANE_X + (used ? r : 0) * XP + c;
+        xf_bits = used ? ((side ? 2 : 1) | (r == 0 ? 4 : 0)) : 8;
+    }
 
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 gst[NG], xst[NX];
+    float4 gst[NG], xst[XF ? NXF : NX];
     constexpr unsigned OOB = 0xFFFFFFF0u;
     auto issue = [&](int tile) {
         int t = tile;
@@ -1810,7 +1831,19 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
                 gst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             }
         }
-        if (RES == NGAN_RESAMPLE_NONE) {
+        if (XF) {
+            const int soff = ((y0 - 1) * a.W + (x0 - 1)) * a.K * 4;                  // negative on the top row / for the first tile
+            const char* base = reinterpret_cast<const char*>(a.x + (long)b * a.H * a.W * a.K) + soff;
+            const unsigned nrec = (unsigned)(a.H * a.W * a.K) * 4u - (unsigned)soff;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, nrec, 0x00020000);
+            // top halo row = the first interior load of the waves holding items e < 32 Q; above the image: no records, zeros
+            const __amdgpu_buffer_rsrc_t rs_top = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (y0 == 0 && wave < (32 * Q) / 64) ? 0u : nrec, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NXINT; ++i)
+                xst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(i == 0 ? rs_top : rs, xf_voff[i], 0, 0));
+            const int bad = (x0 == 0 ? 1 : 0) | (x0 + 32 >= a.W ? 2 : 0) | (y0 == 0 ? 4 : 0) | 8;
+            xst[XF ? NXINT : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (xf_bits & bad) ? OOB : xf_voff[XF ? NXINT : 0], 0, 0));
+        } else if (RES == NGAN_RESAMPLE_NONE) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.H * a.W * a.K), 0,
                                                                                  (unsigned)(a.H * a.W * a.K) * 4u, 0x00020000);
 #pragma unroll
@@ -1840,12 +1873,22 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
             float* d = g_lds + g_l[i];
             d[0] = gst[i].x; d[PLANE_G] = gst[i].y; d[2 * PLANE_G] = gst[i].z; d[3 * PLANE_G] = gst[i].w;
         }
+        if (XF) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
-            if (x_r[i] > -1000) {
-                float* d = x_lds + x_l[i];
-                d[0] = xst[i].x; d[PLANE_X] = xst[i].y; d[2 * PLANE_X] = xst[i].z; d[3 * PLANE_X] = xst[i].w;
-            }
+            for (int i = 0; i < NXF; ++i)
+                if (i < NXINT || tid < N_HALO) {
+                    float* d = x_lds + xf_l[XF ? i : 0];
+                    const float4 v = xst[XF ? i : 0];
+                    d[0] = v.x; d[PLANE_X] = v.y; d[2 * PLANE_X] = v.z; d[3 * PLANE_X] = v.w;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                if (x_r[i] > -1000) {
+                    float* d = x_lds + x_l[i];
+                    d[0] = xst[i].x; d[PLANE_X] = xst[i].y; d[2 * PLANE_X] = xst[i].z; d[3 * PLANE_X] = xst[i].w;
+                }
+        }
         __syncthreads();
         const int tn = tile + gridDim.x;
         if (tn < a.n_tiles) issue(tn);   // next tile's loads are in flight during the MFMAs
@@ -2179,13 +2222,14 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision,
     if (!v1) {
         constexpr int NW = wgrad_f32_waves(COT, CIT);
         if (p.tw == 32) {
-            if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW>), grid, dim3(NW * 64), 0, s, a);
-            else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 1, 32, NW>), grid, dim3(NW * 64), 0, s, a);
-            else hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 2, 32, NW>), grid, dim3(NW * 64), 0, s, a);
+            if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 1>), grid, dim3(NW * 64), 0, s, a);
+            else if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 0>), grid, dim3(NW * 64), 0, s, a);
+            else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 1, 32, NW, 0>), grid, dim3(NW * 64), 0, s, a);
+            else hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 2, 32, NW, 0>), grid, dim3(NW * 64), 0, s, a);
         } else {
-            if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 16, NW>), grid, dim3(NW * 64), 0, s, a);
-            else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 1, 16, NW>), grid, dim3(NW * 64), 0, s, a);
-            else hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 2, 16, NW>), grid, dim3(NW * 64), 0, s, a);
+            if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 16, NW, 0>), grid, dim3(NW * 64), 0, s, a);
+            else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 1, 16, NW, 0>), grid, dim3(NW * 64), 0, s, a);
+            else hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 2, 16, NW, 0>), grid, dim3(NW * 64), 0, s, a);
         }
         return ngan::launch_status("ngan_conv3x3_wgrad(f32)");
     }
@@ -2323,13 +2367,20 @@ extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int
     return ngan::launch_status("ngan_conv3x3_pack_weights");
 }
 
+// NGAN_MID_F32=0: exact-fp32 layers with 32..128 channels on small images go back to the generic kernel (A/B switch)
+static bool mid_f32_enabled() {
+    static const bool on = [] { const char* e = getenv("NGAN_MID_F32"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 extern "C" int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision) {
     if (epilogue == EPI_NONE || epilogue == EPI_LRELU_PN) return 1;
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const bool persist = persist_eligible(B, H, W, K, N, resample);
     if (epilogue == EPI_TO_IMAGE) return persist && resample == 0 && out_mode == 0 ? 1 : 0;
     if (epilogue == EPI_PN_BWD)
-        return (persist && resample == 0) || (precision >= 1 && resample == 0 && ngan::conv3x3_mid_fuses_epilogue(B, H, W, precision == 2 ? 32 : K, N)) ? 1 : 0;
+        return (persist && resample == 0) ||
+               ((precision >= 1 || mid_f32_enabled()) && resample == 0 && ngan::conv3x3_mid_fuses_epilogue(B, H, W, precision == 2 ? 32 : K, N)) ? 1 : 0;
     return 0;
 }
 
@@ -2374,8 +2425,10 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
         return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, precision, s)
                        : dispatch_persist<2, 2>(a, resample, epilogue, out_mode, precision, s);
     }
-    if (precision >= 1)   // many channels, small image: split-bf16 kernel of conv3x3_mid.hip (precision 2: K = 16 padded to 32)
-        return ngan::conv3x3_mid_launch(x, packed, bias, y, rnorm, aux_in, aux_rn, B, H, W, K, N, resample, epilogue, out_mode, slope, eps, s);
+    // many channels, small image: the kernel of conv3x3_mid.hip, split-bf16 (precision 2: K = 16 padded to 32) or exact fp32
+    // (fp32 with a pooled input stays on the generic kernel, which measured 10 % faster there)
+    if (precision >= 1 || (mid_f32_enabled() && resample != NGAN_RESAMPLE_POOL2 && ngan::conv3x3_mid_eligible(B, H, W, K, N)))
+        return ngan::conv3x3_mid_launch(x, packed, bias, y, rnorm, aux_in, aux_rn, B, H, W, K, N, resample, epilogue, out_mode, slope, eps, precision, s);
     // generic exact-fp32 kernel: it has epilogues 0 and 1; the PixelNorm backward runs as a second launch, in place
     const int epi = epilogue == EPI_PN_BWD ? EPI_NONE : epilogue;
     int st;
@@ -2423,8 +2476,8 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
             snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
                      (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision);
     }
-    else if (precision >= 1 && ngan::conv3x3_mid_eligible(B, H, W, precision == 2 ? 32 : K, N))
-        return ngan::conv3x3_mid_kernel_name(B, H, W, precision == 2 ? 32 : K, N, resample, epilogue, out_mode, buf, len);
+    else if ((precision >= 1 || (mid_f32_enabled() && resample != NGAN_RESAMPLE_POOL2)) && ngan::conv3x3_mid_eligible(B, H, W, precision == 2 ? 32 : K, N))
+        return ngan::conv3x3_mid_kernel_name(B, H, W, precision == 2 ? 32 : K, N, resample, epilogue, out_mode, precision, buf, len);
     else {
         const TileCfg c = kCfg[mti][ci];
         snprintf(buf, len, "conv3x3_kernel<%d, %d, %d, %d, %d, %d, %d>", c.mtw, c.wn, c.pgw, c.pcg, out_mode ? 0 : resample,
@@ -2445,7 +2498,8 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
                  "conv3x3_wgrad_kernel_name: bad shape");
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
     if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
-    else snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw, wgrad_f32_waves(p.co_s / 16, p.ci_s / 16));
+    else snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw, wgrad_f32_waves(p.co_s / 16, p.ci_s / 16),
+                  (resample == 0 && p.tw == 32 && W % 32 == 0) ? 1 : 0);
     return NGAN_OK;
 }
 

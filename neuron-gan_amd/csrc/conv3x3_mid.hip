@@ -45,14 +45,18 @@ __device__ __forceinline__ float4 load_inside(const float* __restrict__ x, int b
     }
 }
 
-template <int KG, int PGW, int MTW, int WN>
+// PREC = 1: split bf16 as described above.  PREC = 0: the SAME tiling in exact fp32 -- the LDS pixel holds the K floats as they are,
+// a contraction step is one tap of a 16-channel group (one ds_read_b128 per pixel group, one 16-byte weight fragment per channel
+// tile in the layout of pack_weights_kernel, 4 x v_mfma_f32_16x16x4_f32 per tile), and the weight ring has 9 slots (slot = tap),
+// filled 8 steps ahead, so the loop over channel groups needs no unrolling beyond a pair of groups.
+template <int KG, int PGW, int MTW, int WN, int PREC = 1>
 struct MidCfg {
     static constexpr int WP = 4 / WN;
     static constexpr int K = KG * 32, NS = 16 * MTW * WN;
     static constexpr int PITCH = K * 4 + 16;             // bytes per LDS pixel
     static constexpr int NPIX = 6 * 18;
-    static constexpr int NSTEP = 9 * KG;
-    static constexpr int D = (MTW * PGW >= 8) ? 3 : (MTW * PGW >= 4 ? 5 : 8);   // weight prefetch distance, in steps
+    static constexpr int NSTEP = PREC ? 9 * KG : 18 * KG;
+    static constexpr int D = !PREC ? 8 : (MTW * PGW >= 8) ? 3 : (MTW * PGW >= 4 ? 5 : 8);   // weight prefetch distance, in steps
     static_assert(WP * PGW == 4, "a workgroup covers 4 pixel groups (4 rows x 16 pixels)");
 };
 
@@ -60,9 +64,10 @@ struct MidCfg {
 // are exchanged through LDS.  With one 4-wave workgroup per CU (all these layers offer) every SIMD hosts ONE wave, whose staging
 // VALU, MFMAs and waits simply add up (PMC: 27 % + 24 % + 38 % of the wave's lifetime); two waves per SIMD overlap them and each
 // has half the serial chain.
-template <int KG, int PGW, int MTW, int WN, int EPI, int OUTMODE, int KS>
+template <int KG, int PGW, int MTW, int WN, int EPI, int OUTMODE, int KS, int PREC>
 __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int resample) {
-    using C = MidCfg<KG, PGW, MTW, WN>;
+    using C = MidCfg<KG, PGW, MTW, WN, PREC>;
+    static_assert(PREC == 1 || KS == 1, "the fp32 variant has no contraction split");
     constexpr int K = C::K, PITCH = C::PITCH, NPIX = C::NPIX, NSTEP = C::NSTEP, D = C::D, NT = 256 * KS;
     static_assert(NSTEP % KS == 0, "the contraction steps must split evenly");
     constexpr int OWN = NSTEP / KS;                                     // steps of one wave group
@@ -87,8 +92,8 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
     // ---- weight stream: fragment (step, mt, part) is 64 lanes x 16 B at byte ((step*MT + mt)*2 + part)*1024 + lane*16.  Buffer
     // loads: the lane part is a constant voffset, the (step, mt, part) part a scalar offset -- no per-load vector address math ----
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (unsigned)(9 * K * a.N) * 4u, 0x00020000);   // K, not a.K: the packed layout
-    const unsigned w_voff = (unsigned)(mt0 * 2048 + lane * 16);
-    bf16x8 wr[D + 1][MTW][2];
+    const unsigned w_voff = (unsigned)(mt0 * (PREC ? 2048 : 1024) + lane * 16);
+    bf16x8 wr[PREC ? D + 1 : 1][MTW][2];
     auto wload = [&](int slot, int own_step) {
         const int step = own_step * KS + kh;                            // wave group kh takes steps kh, kh + KS, ...
 #pragma unroll
@@ -98,8 +103,22 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
             wr[slot][mt][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, soff + 1024, 0));
         }
     };
+    // fp32: fragment (tap, g, mt) of pack_weights_kernel is 64 lanes x 16 B at byte ((tap*G + g)*MT + mt)*1024 + lane*16; a fragment
+    // index past the last channel group lands on another valid fragment or beyond the descriptor (zeros) and is never consumed
+    constexpr int G = 2 * KG;
+    f32x4 wf[PREC ? 1 : 9][MTW];
+    auto wload_f32 = [&](int tap, int g) {
 #pragma unroll
-    for (int s = 0; s < D && s < OWN; ++s) wload(s, s);
+        for (int mt = 0; mt < MTW; ++mt)
+            wf[tap][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff, ((tap * G + g) * MT + mt) * 1024, 0));
+    };
+    if (PREC) {
+#pragma unroll
+        for (int s = 0; s < D && s < OWN; ++s) wload(s, s);
+    } else {
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) wload_f32(tap, 0);
+    }
 
     // ---- stage the halo tile, split into bf16 hi / lo.  Branch-free: plain input through a buffer descriptor of the image (an
     // out-of-range offset = conv padding / unused slot reads zeros); resampled input from a clamped address, zeroed afterwards ----
@@ -135,6 +154,10 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
         if (e < NITEM) {
             const int pix = e / CQ, c4 = e % CQ;
             const float4 v = stg[i];
+            if (!PREC) {
+                *reinterpret_cast<float4*>(smem + pix * PITCH + c4 * 16) = v;
+                continue;
+            }
             bf16x4 hi, lo;
             hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
             lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
@@ -154,6 +177,36 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
 
     // this lane's B-operand base: pixel (wp*PGW, p), channel octet q
     const unsigned char* xb = smem + ((wp * PGW) * 18 + p) * PITCH + q * 16;
+    if (!PREC) {
+        // lane (p, q) reads channels 16 g + 4 q + {0..3} of its pixels: component j is the B operand of MFMA j of the step, matching
+        // weight component j (ci = 16 g + 4 q + j) -- the four MFMAs cover the 16 channels in a permuted order, which a sum does not see
+        f32x4 xv[2][PGW];
+        auto xload_f32 = [&](int slot, int g, int tap) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) xv[slot][pg] = *reinterpret_cast<const f32x4*>(xb + ((pg + dy) * 18 + dx) * PITCH + g * 64);
+        };
+        xload_f32(0, 0, 0);
+#pragma unroll 1
+        for (int g2 = 0; g2 < KG; ++g2) {
+#pragma unroll
+            for (int u = 0; u < 18; ++u) {
+                const int g = 2 * g2 + u / 9, tap = u % 9;
+                wload_f32((tap + 8) % 9, tap == 0 ? g : g + 1);                 // step + 8 into the slot consumed one step ago
+                if (u < 17) xload_f32((u + 1) & 1, 2 * g2 + (u + 1) / 9, (u + 1) % 9);
+                else if (g2 + 1 < KG) xload_f32(0, 2 * g2 + 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int pg = 0; pg < PGW; ++pg)
+                            acc[pg][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tap][mt][j], xv[u & 1][pg][j], acc[pg][mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
     bf16x8 xh[2][PGW], xl[2][PGW];      // B operands, read from LDS one step ahead of their MFMAs
     auto xload = [&](int slot, int own_step) {
         const int step = own_step * KS + kh;
@@ -165,9 +218,9 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
             xl[slot][pg] = *reinterpret_cast<const bf16x8*>(src + 64);
         }
     };
-    xload(0, 0);
+    if (PREC) xload(0, 0);
 #pragma unroll
-    for (int s = 0; s < OWN; ++s) {
+    for (int s = 0; s < (PREC ? OWN : 0); ++s) {
         if (s + D < OWN) wload((s + D) % (D + 1), s + D);
         if (s + 1 < OWN) xload((s + 1) & 1, s + 1);
         // keep the prefetches HERE: left alone, the machine scheduler sinks every weight load to just above its first use
@@ -357,27 +410,27 @@ int mid_slice(int n_tiles, int N) {
     return 32;
 }
 
-template <int KG, int PGW, int MTW, int WN>
+template <int KG, int PGW, int MTW, int WN, int PREC>
 int mid_launch_cfg(ConvArgs a, int n_tiles, int n_slices, int resample, int epi, int outmode, hipStream_t s) {
     constexpr int KS = 1;   // KS = 2 (instantiable where KG is even and PGW*MTW <= 4) measured equal within noise in graph replay and
                             // 0-40 % slower per launch under rocprofv3.  Inside a replayed graph a 128->128 launch at 16x16 takes 6.6 us, 6.3 us
                             // with the weight stream switched off (zero-record descriptor): neither the stream nor the wave chain is the limit;
                             // what is left is one memory round trip of staging, ~2 us of MFMAs and the launch itself (tools/micro_graph.py)
     const dim3 grid(n_tiles, n_slices), block(256 * KS);
-    if (epi == EPI_PN_BWD && outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 1, KS>), grid, block, 0, s, a, resample);
-    else if (epi == EPI_PN_BWD) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 0, KS>), grid, block, 0, s, a, resample);
-    else if (outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 1, KS>), grid, block, 0, s, a, resample);
-    else if (epi) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 1, 0, KS>), grid, block, 0, s, a, resample);
-    else hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 0, KS>), grid, block, 0, s, a, resample);
+    if (epi == EPI_PN_BWD && outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 1, KS, PREC>), grid, block, 0, s, a, resample);
+    else if (epi == EPI_PN_BWD) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, EPI_PN_BWD, 0, KS, PREC>), grid, block, 0, s, a, resample);
+    else if (outmode) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 1, KS, PREC>), grid, block, 0, s, a, resample);
+    else if (epi) hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 1, 0, KS, PREC>), grid, block, 0, s, a, resample);
+    else hipLaunchKernelGGL((conv3x3_mid_kernel<KG, PGW, MTW, WN, 0, 0, KS, PREC>), grid, block, 0, s, a, resample);
     return ngan::launch_status("ngan_conv3x3_fwd(mid)");
 }
 
-template <int KG>
+template <int KG, int PREC>
 int mid_launch_kg(const ConvArgs& a, int n_tiles, int ns, int resample, int epi, int outmode, hipStream_t s) {
     const int n_slices = a.N / ns;
-    if (ns == 32) return mid_launch_cfg<KG, 2, 1, 2>(a, n_tiles, n_slices, resample, epi, outmode, s);
-    if (ns == 64) return mid_launch_cfg<KG, 2, 2, 2>(a, n_tiles, n_slices, resample, epi, outmode, s);
-    return mid_launch_cfg<KG, 4, 2, 4>(a, n_tiles, n_slices, resample, epi, outmode, s);
+    if (ns == 32) return mid_launch_cfg<KG, 2, 1, 2, PREC>(a, n_tiles, n_slices, resample, epi, outmode, s);
+    if (ns == 64) return mid_launch_cfg<KG, 2, 2, 2, PREC>(a, n_tiles, n_slices, resample, epi, outmode, s);
+    return mid_launch_cfg<KG, 4, 2, 4, PREC>(a, n_tiles, n_slices, resample, epi, outmode, s);
 }
 
 }  // namespace
@@ -394,16 +447,21 @@ bool conv3x3_mid_fuses_epilogue(int B, int H, int W, int K, int N) {
 
 int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, const float* aux_in,
                        const float* aux_rn, int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                       float slope, float eps, hipStream_t s) {
+                       float slope, float eps, int precision, hipStream_t s) {
     ConvArgs a{x, packed, bias, y, rnorm, B, H, W, K, N, ceil_div(W, 16), ceil_div(H, 4), slope, eps, aux_in, aux_rn, nullptr};
     const int n_tiles = B * a.tiles_x * a.tiles_y;
     const int ns = mid_slice(n_tiles, N);
     const bool fused = epilogue == EPI_NONE || ns == N;      // the channel-reducing epilogues need all N channels in one workgroup
     const int epi = fused ? epilogue : EPI_NONE;
     int st;
-    if (K == 32 || K == 16) st = mid_launch_kg<1>(a, n_tiles, ns, resample, epi, out_mode, s);   // K = 16: padded weights, a.K = 16
-    else if (K == 64) st = mid_launch_kg<2>(a, n_tiles, ns, resample, epi, out_mode, s);
-    else st = mid_launch_kg<4>(a, n_tiles, ns, resample, epi, out_mode, s);
+    if (precision == 0) {
+        if (K == 32) st = mid_launch_kg<1, 0>(a, n_tiles, ns, resample, epi, out_mode, s);
+        else if (K == 64) st = mid_launch_kg<2, 0>(a, n_tiles, ns, resample, epi, out_mode, s);
+        else st = mid_launch_kg<4, 0>(a, n_tiles, ns, resample, epi, out_mode, s);
+    }
+    else if (K == 32 || K == 16) st = mid_launch_kg<1, 1>(a, n_tiles, ns, resample, epi, out_mode, s);   // K = 16: padded weights, a.K = 16
+    else if (K == 64) st = mid_launch_kg<2, 1>(a, n_tiles, ns, resample, epi, out_mode, s);
+    else st = mid_launch_kg<4, 1>(a, n_tiles, ns, resample, epi, out_mode, s);
     if (st || fused) return st;
     // channels were split over workgroups: the epilogue runs as a second, tiny launch over all N channels of a pixel, in place
     const long npix = (long)B * H * W * (out_mode ? 4 : 1);
@@ -411,13 +469,13 @@ int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, f
     return ngan_lrelu_pixelnorm_bwd(y, nullptr, aux_in, aux_rn, y, npix, N, slope, (void*)s);
 }
 
-int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, char* buf, int len) {
+int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision, char* buf, int len) {
     const int n_tiles = B * ceil_div(W, 16) * ceil_div(H, 4);
     const int ns = mid_slice(n_tiles, N);
     const int epi = ns == N ? epilogue : 0;
     const int pgw = ns == 128 ? 4 : 2, mtw = ns == 32 ? 1 : 2, wnn = ns == 128 ? 4 : 2;
     const int ks = 1;
-    snprintf(buf, len, "conv3x3_mid_kernel<%d, %d, %d, %d, %d, %d, %d>", K / 32, pgw, mtw, wnn, epi, out_mode ? 1 : 0, ks);
+    snprintf(buf, len, "conv3x3_mid_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", K / 32, pgw, mtw, wnn, epi, out_mode ? 1 : 0, ks, precision ? 1 : 0);
     return NGAN_OK;
 }
 

@@ -64,6 +64,6 @@ bool conv3x3_mid_eligible(int B, int H, int W, int K, int N);
 bool conv3x3_mid_fuses_epilogue(int B, int H, int W, int K, int N);   // all N channels of a pixel in one workgroup?
 int conv3x3_mid_launch(const float* x, const float* packed, const float* bias, float* y, float* rnorm, const float* aux_in,
                        const float* aux_rn, int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
-                       float slope, float eps, hipStream_t s);
-int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, char* buf, int len);
+                       float slope, float eps, int precision, hipStream_t s);   // precision 0: the exact-fp32 variant
+int conv3x3_mid_kernel_name(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision, char* buf, int len);
 }  // namespace ngan

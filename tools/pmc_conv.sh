@@ -18,7 +18,7 @@ R, tag = sys.argv[1], sys.argv[2]
 tot = {}
 for f in glob.glob(f"{R}/gpurun_out/pmc_{tag}_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "conv3x3" not in r["Kernel_Name"] or "pack" in r["Kernel_Name"]:
+        if ("conv3x3" not in r["Kernel_Name"] and "wgrad_" not in r["Kernel_Name"]) or "pack" in r["Kernel_Name"] or "reduce" in r["Kernel_Name"]:
             continue
         k = (r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])
         d = tot.setdefault(k, [0, 0.0])
