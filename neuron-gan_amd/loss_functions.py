@@ -98,7 +98,9 @@ class D_grad_pen_loss(nn.Module):
         x_hat.requires_grad_()
         output = self.discriminator_net(x_hat)
         # d(sum of the scores)/d(x_hat) (loss_functions.py:175): grad_outputs = ones instead of a sum node
-        Disc_grad = torch.autograd.grad(outputs=output, inputs=x_hat, grad_outputs=self._ones(output), create_graph=True)[0]
+        # (inputs_only: x_hat is the only input asked for, so the critic's weight gradients of this pass would be thrown away)
+        with ops.inputs_only():
+            Disc_grad = torch.autograd.grad(outputs=output, inputs=x_hat, grad_outputs=self._ones(output), create_graph=True)[0]
         penalty, norms = ops.GradPenaltyHead.apply(Disc_grad, float(self.Lambda))
         self.last_grad_norms = norms.detach()
         return penalty

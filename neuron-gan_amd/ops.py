@@ -58,6 +58,32 @@ def first_order_enabled():
     return _first_order > 0 and _first_order_allowed
 
 
+_inputs_only = 0
+
+
+class inputs_only:
+    """Inside, backward passes produce input gradients only; weight and bias gradients are skipped.
+
+    For `torch.autograd.grad(outputs, inputs=<an activation>)`, i.e. the gradient penalty's d D(x_hat) / d x_hat
+    (reference loss_functions.py:170-176).  The engine hands the built-in conv backward of the reference an output mask, so no
+    weight gradient is computed there; a custom Function only sees `needs_input_grad`, which mirrors `requires_grad`, and would
+    spend a full weight-gradient contraction per layer on a result the engine then drops."""
+
+    def __enter__(self):
+        global _inputs_only
+        _inputs_only += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _inputs_only
+        _inputs_only -= 1
+        return False
+
+
+def _param_grads_wanted():
+    return _inputs_only == 0
+
+
 class PNLink:
     """Hand-off between the LeakyReLU->PixelNorm that produced a tensor (y, rn) and the single conv consuming it.  The consumer's
     backward sets `fused` after it has applied the producer's LeakyReLU->PixelNorm backward to the gradient it returns.
@@ -346,12 +372,12 @@ def _conv_backward_tail(ctx, x, weight, gc, resample, scale, in_link, has_bias, 
                 in_link.fused = False        # (a create_graph pass after a plain one on a retained graph)
             gx = ConvDgrad.apply(gc, weight, resample, scale)
     gw = None
-    if ctx.needs_input_grad[1]:
+    if ctx.needs_input_grad[1] and _param_grads_wanted():
         if _accumulates_in_place(weight):
             _run_wgrad(x, _c(gc), resample, scale, accumulate_into=weight.grad)   # weight.grad += ..., returns None to autograd
         else:
             gw = ConvWgrad.apply(x, gc, resample, scale)
-    gb = ChannelSum.apply(gc) if (has_bias and ctx.needs_input_grad[bias_index]) else None
+    gb = ChannelSum.apply(gc) if (has_bias and ctx.needs_input_grad[bias_index] and _param_grads_wanted()) else None
     return gx, gw, gb
 
 
@@ -471,8 +497,8 @@ class Conv(Function):
         x, weight = ctx.saved_tensors
         resample, scale = ctx.cfg
         gx = ConvDgrad.apply(g, weight, resample, scale) if ctx.needs_input_grad[0] else None
-        gw = ConvWgrad.apply(x, g, resample, scale) if ctx.needs_input_grad[1] else None
-        gb = ChannelSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gw = ConvWgrad.apply(x, g, resample, scale) if (ctx.needs_input_grad[1] and _param_grads_wanted()) else None
+        gb = ChannelSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[2] and _param_grads_wanted()) else None
         return gx, gw, gb, None, None
 
 
@@ -561,7 +587,7 @@ class LReLUPN(Function):
         if gy is None:
             gy = torch.zeros_like(y)
         gc = LReLUPNBwd.apply(gy, gr, y, rn, ctx.slope)
-        gb = ChannelSum.apply(gc) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        gb = ChannelSum.apply(gc) if (ctx.has_bias and ctx.needs_input_grad[1] and _param_grads_wanted()) else None
         return gc, gb, None
 
 
@@ -639,7 +665,7 @@ class FromImage(Function):
         x, w = ctx.saved_tensors
         gx = FromImageDx.apply(g, w, ctx.pool) if ctx.needs_input_grad[0] else None
         gw = gb = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and _param_grads_wanted():
             gw, gb = FromImageDw.apply(x, g, ctx.pool, tuple(w.shape))
             if not ctx.has_bias:
                 gb = None
@@ -958,7 +984,7 @@ class FinalDot(Function):
         y, weight = ctx.saved_tensors
         gy = FinalDotDx.apply(go, weight, ctx.scale, tuple(y.shape)) if ctx.needs_input_grad[0] else None
         gw = gb = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and _param_grads_wanted():
             gw, gb = FinalDotDw.apply(y, go, ctx.scale, tuple(weight.shape))
             if not ctx.has_bias:
                 gb = None

@@ -340,6 +340,36 @@ def epoch_fixture(models):
     print("epochs_small.npz:", out["rows"][:, [0, 1, 3, 7]].tolist())
 
 
+# ------------------------------------------------------------------------------------------
+# sampling / eval: utils.gen_samples (utils.py:346-355) and the image part of plot_gen_samples (utils.py:568-601)
+# over the reference's own Generator_PG.  utils.py does not import here (torchvision), so its seeded latent branch
+# (utils.py:57-92: save the global RNG state, manual_seed(seed), draw, restore) is replayed line by line below.
+# ------------------------------------------------------------------------------------------
+def sampling_fixture(models, seed=3, n_images=6):
+    torch.manual_seed(23)
+    G = models.Generator_PG(list(SMALL["g_widths"]), image_size_init=SMALL["image_size_init"], latent_dim=SMALL["latent_dim"])
+    G.to(torch.device("cpu"), torch.float32)
+    G.set_resolution(8, 1.0)                                  # below image_size_max = 16: the enlargement branch runs
+    out = state_np(G, "G/")
+    torch.manual_seed(99)
+    before = torch.get_rng_state()
+    rng_state = torch.get_rng_state()                          # utils.py:66-67
+    torch.manual_seed(seed)
+    z = latent(n_images, G.latent_dim)                         # utils.py:77-78
+    torch.set_rng_state(rng_state)                             # utils.py:84
+    assert torch.equal(before, torch.get_rng_state())
+    was_training = G.training
+    G.train(False)                                             # utils.py:571-572
+    with torch.no_grad():
+        images = G(z).detach()                                 # utils.py:352-353
+    G.train(was_training)
+    enlarged = torch.nn.functional.interpolate(images.cpu(), size=(G.image_size_max, G.image_size_max))   # utils.py:598-601
+    out.update(z=z.numpy(), images=images.numpy(), enlarged=enlarged.numpy(),
+               meta=np.array([8, seed, n_images, G.image_size_max, SMALL["image_size_init"], SMALL["latent_dim"]], dtype=np.float64))
+    np.savez_compressed(os.path.join(OUT, "sampling_small.npz"), **out)
+    print("sampling_small.npz: images", tuple(images.shape), "mean", float(images.mean()), "enlarged", tuple(enlarged.shape))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also regenerate the full-width C3/C4 pins (about a minute of CPU)")
@@ -358,6 +388,8 @@ def main():
         checkpoint_fixtures(models)
     if not only or "epochs" in only:
         epoch_fixture(models)
+    if not only or "sampling" in only:
+        sampling_fixture(models)
     for name in (["C1", "C2"] + (["C3", "C4", "C5"] if args.full else [])):
         if not only or name in only:
             full_fixture(models, config, name)

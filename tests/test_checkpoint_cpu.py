@@ -89,3 +89,27 @@ def test_image_grid_and_cli_parser(ngan):
     ds.set_image_size(4)
     assert tuple(ds[0].shape) == (1, 4, 4) and len(ds) == 6
     assert torch.allclose(ds[0], torch.nn.functional.avg_pool2d(ds.full[0:1], 4)[0], atol=1e-6)
+
+
+def test_seeded_sampling_latents_follow_the_reference(ngan):
+    """gen_samples' latent draw (reference utils.py:346-355 over 57-92) against tests/golden/sampling_small.npz, which
+    oracle/make_golden.py captured over the reference's Generator_PG: same vectors bit for bit, global RNG stream untouched,
+    second call served from the memo."""
+    from conftest import load_golden
+    fix = load_golden("sampling_small")
+    res, seed, n, size_max, init, latent = (int(v) for v in fix["meta"])
+    ngan.utils.Latent_vecs_memo.clear()
+    torch.manual_seed(1234)
+    before = torch.get_rng_state()
+    z = ngan.utils.sample_latent_vec((n, latent), seed=seed)
+    assert torch.equal(before, torch.get_rng_state())
+    assert np.array_equal(z.numpy(), fix["z"])
+    assert ngan.utils.sample_latent_vec((n, latent), seed=seed) is not None and ((n, latent), "randn", seed) in ngan.utils.Latent_vecs_memo
+    # the grid: nearest-neighbour enlargement (utils.py:598-601) laid out row-major with the normalisation of save_image(normalize=True)
+    images = torch.from_numpy(fix["images"])
+    enlarged = torch.nn.functional.interpolate(images, size=(size_max, size_max))
+    assert np.array_equal(enlarged.numpy(), fix["enlarged"])
+    grid = ngan.utils.make_image_grid(enlarged, nrow=int(np.round(np.sqrt(n))))
+    lo, hi = float(enlarged.min()), float(enlarged.max())
+    tile = grid[0, 2:2 + size_max, 2 + (size_max + 2):2 + (size_max + 2) + size_max]          # second image of the first row
+    assert torch.allclose(tile, (enlarged[1, 0] - lo) / (hi - lo), atol=1e-6)

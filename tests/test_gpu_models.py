@@ -292,3 +292,24 @@ def test_reference_inner_loop_verbatim_over_the_drop_in_modules(ngan, name, conv
     for k, v in split_state(fix, "G_after/").items():
         if v.ndim:
             assert adam_close(Generator_net.state_dict()[k].cpu().numpy(), v, lr), ("G after Adam", k)
+
+
+def test_seeded_samples_match_the_reference_generator(ngan):
+    """utils.gen_samples / plot_gen_samples (reference utils.py:346-355, 568-601) on the HIP generator against
+    tests/golden/sampling_small.npz (images the reference's Generator_PG made from the same seeded latents, eval mode, no_grad, and
+    their nearest-neighbour enlargement to image_size_max).  Images within 1e-4 (tanh outputs)."""
+    fix = load_golden("sampling_small")
+    res, seed, n, size_max, init, latent = (int(v) for v in fix["meta"])
+    G = ngan.models.Generator_PG([32, 16, 16], image_size_init=init, latent_dim=latent)
+    G.set_resolution(res, 1.0)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "G/").items()})
+    G = G.to(DEV)
+    ngan.utils.Latent_vecs_memo.clear()
+    G.train(True)
+    images, z = ngan.utils.gen_samples(G, N_images=n, seed=seed)
+    assert np.array_equal(z.cpu().numpy(), fix["z"]) and not images.requires_grad
+    assert np.abs(images.cpu().numpy() - fix["images"]).max() < 1e-4
+    grid = ngan.utils.plot_gen_samples(G, N_images=n, seed=seed)
+    assert G.training                                                        # the caller's mode is restored (utils.py:571-583)
+    want = ngan.utils.make_image_grid(torch.from_numpy(fix["enlarged"]), nrow=int(np.round(np.sqrt(n))))
+    assert grid.shape == want.shape and float((grid - want).abs().max()) < 2e-4

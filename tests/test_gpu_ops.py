@@ -603,3 +603,51 @@ def test_loss_heads_and_latent_projection_match_torch(ngan):
     got = ops.latent_normalize_(z.to(DEV).clone(), 5.0).cpu()
     zc = z.clamp(-5, 5)
     assert rel(got, zc / zc.norm(p=2, dim=1, keepdim=True)) < 1e-6
+
+
+def test_inputs_only_skips_parameter_gradients(ngan, monkeypatch):
+    """`ops.inputs_only()` (used around the gradient penalty's autograd.grad w.r.t. x_hat, reference loss_functions.py:170-176): the
+    input gradient and everything differentiated from it later are bit-identical to the plain pass, and no weight-gradient or
+    bias-sum kernel is launched for results the engine would drop."""
+    ops = ngan.ops
+    torch.manual_seed(8)
+    x = nhwc(torch.randn(2, 16, 32, 32)).to(DEV)
+    w1 = (torch.randn(32, 16, 3, 3)).to(DEV).requires_grad_()
+    b1 = torch.randn(32).to(DEV).requires_grad_()
+    w2 = (torch.randn(16, 32, 3, 3)).to(DEV).requires_grad_()
+    calls = {"wgrad": 0, "sum": 0}
+    real_wgrad, real_sum = ops._run_wgrad, ops._channel_sum
+
+    def count_wgrad(*a, **k):
+        calls["wgrad"] += 1
+        return real_wgrad(*a, **k)
+
+    def count_sum(*a, **k):
+        calls["sum"] += 1
+        return real_sum(*a, **k)
+
+    monkeypatch.setattr(ops, "_run_wgrad", count_wgrad)
+    monkeypatch.setattr(ops, "_channel_sum", count_sum)
+
+    def penalty(inputs_only):
+        xx = x.clone().requires_grad_()
+        y, _ = ops.ConvLReLUPN.apply(xx, w1, b1, 0, 0.1, SLOPE)
+        out = ops.Conv.apply(y, w2, None, 0, 0.1)
+        ones = torch.ones_like(out)
+        calls["wgrad"] = calls["sum"] = 0
+        if inputs_only:
+            with ops.inputs_only():
+                gx = torch.autograd.grad(out, xx, ones, create_graph=True)[0]
+        else:
+            gx = torch.autograd.grad(out, xx, ones, create_graph=True)[0]
+        first = dict(calls)
+        gw = torch.autograd.grad(gx.square().sum(), [w1, b1, w2])
+        return gx.detach(), gw, first
+
+    gx0, gw0, first0 = penalty(False)
+    gx1, gw1, first1 = penalty(True)
+    assert first0["wgrad"] == 2 and first0["sum"] >= 1           # what a custom Function does when it cannot see the output mask
+    assert first1 == {"wgrad": 0, "sum": 0}
+    assert torch.equal(gx0, gx1)
+    for a, b in zip(gw0, gw1):
+        assert torch.equal(a, b)
