@@ -141,9 +141,10 @@ class ConvProbe:
 
 def is_split_bf16_instance(name):
     """does this kernel template instance compute its products on the bf16 MFMA (HBM is then the binding roof)?"""
-    if "mid_kernel" in name or "up2f" in name or "wgrad_bf16x3" in name:
+    if "up2f" in name or "wgrad_bf16x3" in name:
         return True
-    return ("persist" in name or "tile_kernel" in name) and name.rstrip(">").endswith(", 1")     # last template argument: PREC
+    # last template argument of these three: PREC
+    return ("persist" in name or "tile_kernel" in name or "mid_kernel" in name) and name.rstrip(">").endswith(", 1")
 
 
 def build_nets(pkg, res, alpha, device):

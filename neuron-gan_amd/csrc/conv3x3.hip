@@ -2519,10 +2519,12 @@ constexpr int kReduceBatch = 24;
 struct ReduceBatch { ReduceEntry e[kReduceBatch]; int n; };
 
 // One workgroup sums kReduceSpan consecutive elements of a gradient over all slabs: a wave reads 256 contiguous bytes of one slab
-// per load (whole cache lines; 16-element spans fetched half-used 128-byte lines), the 4 waves take every 4th slab each.
-constexpr int kReduceSpan = 64;
-__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(ReduceBatch b) {
-    __shared__ float red[256];
+// per load (whole cache lines; 16-element spans fetched half-used 128-byte lines), the waves take every 16th slab each.
+// 16 waves per workgroup: a 16-channel layer has 512 slabs per source and only 36 spans, so the launch is bound by the CHAIN of
+// dependent round trips per wave (128 loads, 8 in flight, x 3 sources with 4 waves: ~100 us measured); 16 waves cut the chain by 4.
+constexpr int kReduceSpan = 64, kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void wgrad_reduce_many_kernel(ReduceBatch b) {
+    __shared__ float red[kReduceThreads];
     int ei = 0;
     for (int i = 1; i < b.n; ++i)
         if ((int)blockIdx.x >= b.e[i].first_block) ei = i;
@@ -2530,7 +2532,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(ReduceBatch b) {
     const int slab = 9 * e.co_s * e.ci_s;
     const long M = (long)e.nslices * slab;
     const int tid = threadIdx.x, el = tid & (kReduceSpan - 1), grp = tid / kReduceSpan;
-    constexpr int NG = 256 / kReduceSpan;
+    constexpr int NG = kReduceThreads / kReduceSpan;
     const long i = (long)(blockIdx.x - e.first_block) * kReduceSpan + el;
     float total = 0.f;
     for (int s = 0; s < e.nsrc; ++s) {
@@ -2602,7 +2604,7 @@ extern "C" int ngan_conv3x3_wgrad_reduce_many(const void* entries, int n, void* 
             b.e[i].first_block = blocks;
             blocks += ngan::ceil_div((long)b.e[i].nslices * 9 * b.e[i].co_s * b.e[i].ci_s, kReduceSpan);
         }
-        hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+        hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(blocks), dim3(kReduceThreads), 0, (hipStream_t)stream, b);
         int st = ngan::launch_status("ngan_conv3x3_wgrad_reduce_many");
         if (st) return st;
     }

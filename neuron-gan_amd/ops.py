@@ -719,14 +719,17 @@ class FirstBlock(Function):
             gc = torch.empty_like(y)
             _C.call("ngan_lrelu_pixelnorm_bwd", _c(gy), None, y, rn, gc, y.numel() // n, n, float(slope))
         dev = y.device
-        ws = torch.empty(_C.lib().ngan_first_block_workspace_floats(b, h, n), device=dev, dtype=torch.float32)
-        in_place = ctx.needs_input_grad[3] and _accumulates_in_place(weight)
-        gw = weight.grad if in_place else torch.empty_like(weight)
-        gwf = torch.empty_like(w_from)
-        gbf = torch.empty_like(b_from) if b_from is not None else None
-        gb = torch.empty(n, device=dev, dtype=torch.float32) if has_bias else None
-        _C.call("ngan_first_block_bwd", p, gc, weight.detach(), w_from.detach().reshape(c), b_from, gw, gwf, gbf, gb, ws,
-                b, h, wd, c, n, float(scale), 1 if in_place else 0)
+        in_place = False
+        gw = gwf = gbf = gb = None
+        if any(ctx.needs_input_grad[1:5]) and _param_grads_wanted():     # (not in the generator step: the critic is frozen there)
+            ws = torch.empty(_C.lib().ngan_first_block_workspace_floats(b, h, n), device=dev, dtype=torch.float32)
+            in_place = ctx.needs_input_grad[3] and _accumulates_in_place(weight)
+            gw = weight.grad if in_place else torch.empty_like(weight)
+            gwf = torch.empty_like(w_from)
+            gbf = torch.empty_like(b_from) if b_from is not None else None
+            gb = torch.empty(n, device=dev, dtype=torch.float32) if has_bias else None
+            _C.call("ngan_first_block_bwd", p, gc, weight.detach(), w_from.detach().reshape(c), b_from, gw, gwf, gbf, gb, ws,
+                    b, h, wd, c, n, float(scale), 1 if in_place else 0)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty((b, 2 * h, 2 * wd, 1) if pool else (b, h, wd, 1), device=dev, dtype=torch.float32)
