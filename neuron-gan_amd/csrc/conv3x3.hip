@@ -246,8 +246,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             v[pg][mt] = c;
         }
         if (EPI == 1) {
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            ss = sum_rows4(ss);
         }
         ssum[pg] = ss;
     }
@@ -699,8 +698,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 v[mt] = c;
             }
             if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE) {
-                ss += __shfl_xor(ss, 16, 64);
-                ss += __shfl_xor(ss, 32, 64);
+                ss = sum_rows4(ss);
                 const float m = ss * inv_n + a.eps;
                 const float inv = __builtin_amdgcn_rsqf(m);
 #pragma unroll
@@ -712,8 +710,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 float d = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) d += f4dot(v[mt], wimg[mt]);
-                d += __shfl_xor(d, 16, 64);
-                d += __shfl_xor(d, 32, 64);
+                d = sum_rows4(d);
                 if (q == pg) timg = d;          // all four q-lanes hold pixel group pg's sum; lane group q keeps the one it will finish
             }
             if (EPI == EPI_PN_BWD && OUTMODE == 0) {
@@ -726,8 +723,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 float s = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) s += f4dot(v[mt], yy[mt]);
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
+                s = sum_rows4(s);
                 s *= inv_n;
                 const float inv_r = 1.0f / rr;
 #pragma unroll
@@ -776,8 +772,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                             yy[mt] = yy4[EPI == EPI_PN_BWD ? sub : 0][mt];
                             s += f4dot(o4[mt], yy[mt]);
                         }
-                        s += __shfl_xor(s, 16, 64);
-                        s += __shfl_xor(s, 32, 64);
+                        s = sum_rows4(s);
                         s *= inv_n;
                         const float inv_r = 1.0f / rr4[EPI == EPI_PN_BWD ? sub : 0];
 #pragma unroll
@@ -995,10 +990,10 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         const unsigned y_soff = (unsigned)pix0 * (N * 4), p_soff = (unsigned)(y0 * a.W + x0) * 4u;
         const unsigned out_bytes = (unsigned)(OS * a.H * Wo * N) * 4u, px_bytes = (unsigned)(a.H * a.W) * 4u;
         __amdgpu_buffer_rsrc_t y_rsrc, rn_rsrc, ay_rsrc, arn_rsrc;
-        if (EPI != EPI_TO_IMAGE || a.y) {
-            y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img * (OS * OS) * N, 0, out_bytes, 0x00020000);
-            if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE) rn_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rn + img, 0, px_bytes, 0x00020000);
-        }
+        if (EPI != EPI_TO_IMAGE || a.y) y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img * (OS * OS) * N, 0, out_bytes, 0x00020000);
+        // (no stored activation -- the inference form of epilogue 3 -- means no stored norm either: a descriptor without records)
+        if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE)
+            rn_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rn + img, 0, (EPI == EPI_LRELU_PN || a.y) ? px_bytes : 0u, 0x00020000);
         if (EPI == EPI_PN_BWD) {
             ay_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ay) + img * (OS * OS) * N, 0, out_bytes, 0x00020000);
             arn_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.arn) + img * (OS * OS), 0, (unsigned)(OS * a.H * Wo) * 4u, 0x00020000);
@@ -1111,15 +1106,15 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                     sq = __builtin_elementwise_fma(hi[mt], hi[mt], sq);
                 }
                 float ss = sq.x + sq.y;
-                ss += __shfl_xor(ss, 16, 64);
-                ss += __shfl_xor(ss, 32, 64);
+                ss = sum_rows4(ss);
                 const float m = ss * inv_n + a.eps;
                 const float inv = __builtin_amdgcn_rsqf(m);
                 const f32x2 inv2 = {inv, inv};
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) { lo[mt] *= inv2; hi[mt] *= inv2; }
-                if ((EPI == EPI_LRELU_PN || a.y) && q == 0)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m * inv), rn_rsrc, (e_voff[pg] >> NSHIFT) + p_soff, 0, 0);
+                // the norm: one lane per pixel stores, the others' offset is out of range (a branch here would also cut the epilogue
+                // into basic blocks and keep the four pixel groups' reduction chains from being scheduled side by side)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m * inv), rn_rsrc, q == 0 ? (e_voff[pg] >> NSHIFT) + p_soff : OOB, 0, 0);
             }
             if (EPI == EPI_TO_IMAGE) {
                 f32x2 d2 = {0.f, 0.f};
@@ -1129,8 +1124,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                     d2 = __builtin_elementwise_fma(hi[mt], (f32x2){wimg[mt].z, wimg[mt].w}, d2);
                 }
                 float d = d2.x + d2.y;
-                d += __shfl_xor(d, 16, 64);
-                d += __shfl_xor(d, 32, 64);
+                d = sum_rows4(d);
                 if (q == pg) timg = d;          // all four q-lanes hold pixel group pg's sum; lane group q keeps the one it will finish
             }
             if (PNB) {
@@ -1141,8 +1135,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                     const float4 y4 = yy[PNB ? pg : 0][mt];
                     s += lo[mt].x * y4.x + lo[mt].y * y4.y + hi[mt].x * y4.z + hi[mt].y * y4.w;
                 }
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
+                s = sum_rows4(s);
                 s *= inv_n;
                 const float inv_r = 1.0f / rr[PNB ? pg : 0];
 #pragma unroll
@@ -1194,8 +1187,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                         float s = 0.f;
 #pragma unroll
                         for (int mt = 0; mt < MTW; ++mt) s += f4dot(o4[mt], y4s[EPI == EPI_PN_BWD ? sub : 0][mt]);
-                        s += __shfl_xor(s, 16, 64);
-                        s += __shfl_xor(s, 32, 64);
+                        s = sum_rows4(s);
                         s *= inv_n;
                         const float inv_r = 1.0f / r4s[EPI == EPI_PN_BWD ? sub : 0];
 #pragma unroll
@@ -1358,8 +1350,7 @@ __global__ __launch_bounds__(256, KG == 1 ? 3 : 2) void conv3x3_up2f_kernel(Conv
                 c.x = fmaxf(c.x, a.slope * c.x); c.y = fmaxf(c.y, a.slope * c.y);
                 c.z = fmaxf(c.z, a.slope * c.z); c.w = fmaxf(c.w, a.slope * c.w);
                 float ss = f4dot(c, c);
-                ss += __shfl_xor(ss, 16, 64);
-                ss += __shfl_xor(ss, 32, 64);
+                ss = sum_rows4(ss);
                 const float m = ss * inv_n + a.eps;
                 const float inv = __builtin_amdgcn_rsqf(m);
                 c = f4scale(c, inv);

@@ -272,8 +272,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
     auto pixel_sum = [&](float (&part)[PGW]) {
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg) {
-            part[pg] += __shfl_xor(part[pg], 16, 64);
-            part[pg] += __shfl_xor(part[pg], 32, 64);
+            part[pg] = sum_rows4(part[pg]);
         }
         if (WN > 1) {
             __syncthreads();           // ss_l may still be read from a previous call

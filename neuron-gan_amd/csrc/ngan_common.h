@@ -57,6 +57,21 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Sum over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48); every lane ends with the total.  The same two
+// additions as `v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)` -- bit-identical -- but on gfx950's row / half swaps
+// (v_permlane16_swap: odd rows of the first register <-> even rows of the second; v_permlane32_swap: upper half <-> lower half),
+// which are VALU instructions: the shuffles compile to ds_bpermute_b32, an LDS round trip with a full `s_waitcnt lgkmcnt(0)` each,
+// i.e. two serial LDS latencies per pixel group in every PixelNorm epilogue.  (Inline asm: the builtin's second result came back
+// aliased to the first in this compiler.)  s_nop 1: the swap reads its operands as a VALU-written pair.
+__device__ __forceinline__ float sum_rows4(float v) {
+    float w = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+    v += w;
+    w = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+    return v + w;
+}
+
 // Bilinear x2 (align_corners=False) source taps for output index d (0 <= d < 2n):
 // out[d] = w0*in[i0] + w1*in[i1]     (models.py:87-89 -> ATen upsample_bilinear2d)
 __device__ __forceinline__ void up2_taps(int d, int n, int& i0, int& i1, float& w0, float& w1) {
