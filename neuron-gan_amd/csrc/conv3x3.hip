@@ -691,8 +691,8 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 float4 c = make_float4(acc[pg][mt][0] + bv[mt].x, acc[pg][mt][1] + bv[mt].y,
                                        acc[pg][mt][2] + bv[mt].z, acc[pg][mt][3] + bv[mt].w);
                 if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE) {
-                    c.x = fmaxf(c.x, a.slope * c.x); c.y = fmaxf(c.y, a.slope * c.y);   // LeakyReLU, 0 <= slope <= 1
-                    c.z = fmaxf(c.z, a.slope * c.z); c.w = fmaxf(c.w, a.slope * c.w);
+                    c.x = vmax1(c.x, a.slope * c.x); c.y = vmax1(c.y, a.slope * c.y);   // LeakyReLU, 0 <= slope <= 1
+                    c.z = vmax1(c.z, a.slope * c.z); c.w = vmax1(c.w, a.slope * c.w);
                     ss += f4dot(c, c);
                 }
                 v[mt] = c;
@@ -1099,9 +1099,9 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                 f32x2 sq = {0.f, 0.f};
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
-                    const f32x2 sl = lo[mt] * slope2, sh = hi[mt] * slope2;            // LeakyReLU, 0 <= slope <= 1 (fmaxf: one v_max each;
-                    lo[mt] = (f32x2){fmaxf(lo[mt].x, sl.x), fmaxf(lo[mt].y, sl.y)};     //  __builtin_elementwise_max adds a canonicalising v_max)
-                    hi[mt] = (f32x2){fmaxf(hi[mt].x, sh.x), fmaxf(hi[mt].y, sh.y)};
+                    const f32x2 sl = lo[mt] * slope2, sh = hi[mt] * slope2;            // LeakyReLU, 0 <= slope <= 1 (vmax1: one v_max each;
+                    lo[mt] = (f32x2){vmax1(lo[mt].x, sl.x), vmax1(lo[mt].y, sl.y)};     //  __builtin_elementwise_max adds a canonicalising v_max)
+                    hi[mt] = (f32x2){vmax1(hi[mt].x, sh.x), vmax1(hi[mt].y, sh.y)};
                     sq = mt == 0 ? lo[mt] * lo[mt] : __builtin_elementwise_fma(lo[mt], lo[mt], sq);
                     sq = __builtin_elementwise_fma(hi[mt], hi[mt], sq);
                 }
@@ -1347,8 +1347,8 @@ __global__ __launch_bounds__(256, KG == 1 ? 3 : 2) void conv3x3_up2f_kernel(Conv
             const bool valid = gy > 0 && gy < a.H - 1 && gx > 0 && gx < a.W - 1;
             float4 c = make_float4(acc[r][0] + bv.x, acc[r][1] + bv.y, acc[r][2] + bv.z, acc[r][3] + bv.w);
             if (EPI == EPI_LRELU_PN) {
-                c.x = fmaxf(c.x, a.slope * c.x); c.y = fmaxf(c.y, a.slope * c.y);
-                c.z = fmaxf(c.z, a.slope * c.z); c.w = fmaxf(c.w, a.slope * c.w);
+                c.x = vmax1(c.x, a.slope * c.x); c.y = vmax1(c.y, a.slope * c.y);
+                c.z = vmax1(c.z, a.slope * c.z); c.w = vmax1(c.w, a.slope * c.w);
                 float ss = f4dot(c, c);
                 ss = sum_rows4(ss);
                 const float m = ss * inv_n + a.eps;
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(256) void conv3x3_up2_border_kernel(ConvArgs a, con
     float c = (c0 + c1) + (c2 + c3);
     float r = 1.f;
     if (EPI == EPI_LRELU_PN) {
-        c = fmaxf(c, a.slope * c);
+        c = vmax1(c, a.slope * c);
         const float ss = group_sum<16>(c * c);
         r = sqrtf(ss / (float)N + a.eps);
         c /= r;

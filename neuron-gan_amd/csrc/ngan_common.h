@@ -57,6 +57,14 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// max(a, b) as ONE v_max_f32.  fmaxf() first canonicalises each operand (a `v_max_f32 x, x, x` apiece: 4 extra VALU instructions
+// per LeakyReLU of a float4); the values fed here are MFMA accumulators and products, canonical already.  NaN in -> NaN out as before.
+__device__ __forceinline__ float vmax1(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Sum over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48); every lane ends with the total.  The same two
 // additions as `v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)` -- bit-identical -- but on gfx950's row / half swaps
 // (v_permlane16_swap: odd rows of the first register <-> even rows of the second; v_permlane32_swap: upper half <-> lower half),
