@@ -1742,17 +1742,23 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
     constexpr int PLANE_G = pad_plane(TH * TW), PLANE_X = pad_plane(HALO_H * XP);
     constexpr int G_ELEMS = CO_S * PLANE_G, X_ELEMS = CI_S * PLANE_X;
     constexpr int RED_ELEMS = NW * 9 * 64 * 4;
-    constexpr int SMEM = (G_ELEMS + X_ELEMS) > RED_ELEMS ? (G_ELEMS + X_ELEMS) : RED_ELEMS;
+    // bilinear input: the low-resolution source patch of the halo tile is loaded once (fp32, [py][px][CI_S]) and expanded LDS -> LDS,
+    // as in wgrad_bf16x3_kernel: 2 global loads per thread instead of 24, and the tap / weight arithmetic is tile-invariant
+    constexpr int PH = TH / 2 + 2, PW = TW / 2 + 2, NPP = PH * PW;
+    constexpr int PATCH_ELEMS = RES == NGAN_RESAMPLE_UP2 ? NPP * CI_S : 0;
+    constexpr int SMEM = (G_ELEMS + X_ELEMS + PATCH_ELEMS) > RED_ELEMS ? (G_ELEMS + X_ELEMS + PATCH_ELEMS) : RED_ELEMS;
     constexpr int NG = TH * TW * (CO_S / 4) / NT, NXI = HALO_H * (TW + 2) * (CI_S / 4), NX = (NXI + NT - 1) / NT;
     static_assert(TH * TW * (CO_S / 4) % NT == 0 && TH % WR == 0 && NW % WO == 0, "tile split");
     // XF: plain input on an image whose width is a multiple of the 32-pixel tile -- the x tile is staged like conv3x3_tile_kernel's
     // (interior columns by whole loads at constant per-lane offsets, the descriptor base moved per tile, the top halo row behind a
     // zero-record descriptor, the two halo columns in one extra load): ~50 fewer VALU instructions per wave and tile
     constexpr int Q = CI_S / 4, NXINT = HALO_H * 32 * Q / NT, NXF = NXINT + 1, N_HALO = 2 * HALO_H * Q;
+    constexpr int NPI = NPP * Q, NXP = (NPI + NT - 1) / NT;                      // patch float4s, per thread
     static_assert(!XF || (RES == NGAN_RESAMPLE_NONE && TW == 32 && (HALO_H * 32 * Q) % NT == 0 && N_HALO <= NT), "fast x staging");
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* g_lds = smem;
     float* x_lds = smem + G_ELEMS;
+    float* patch = smem + G_ELEMS + X_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
@@ -1800,7 +1806,7 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 gst[NG], xst[XF ? NXF : NX];
+    float4 gst[NG], xst[XF ? NXF : (RES == NGAN_RESAMPLE_UP2 ? NXP : NX)];
     constexpr unsigned OOB = 0xFFFFFFF0u;
     auto issue = [&](int tile) {
         int t = tile;
@@ -1844,6 +1850,18 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
                 const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.K + x_ch) * 4) : OOB;
                 xst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             }
+        } else if (RES == NGAN_RESAMPLE_UP2) {
+            const int h = a.H >> 1, w = a.W >> 1;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * h * w * a.K), 0,
+                                                                                 (unsigned)(h * w * a.K) * 4u, 0x00020000);
+            const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;      // patch row 0 / column 0; clamped coordinates = the taps' edge rule
+#pragma unroll
+            for (int i = 0; i < NXP; ++i) {
+                const int e = tid + i * NT, pix = e / Q, c4 = e % Q;
+                const int ly = min(max(ly0 + pix / PW, 0), h - 1), lx = min(max(lx0 + pix % PW, 0), w - 1);
+                const unsigned off = e < NPI ? (unsigned)(((ly * w + lx) * a.K + ci0 + c4 * 4) * 4) : OOB;
+                xst[RES == NGAN_RESAMPLE_UP2 ? i : 0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NX; ++i)
@@ -1870,6 +1888,31 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
                 if (i < NXINT || tid < N_HALO) {
                     float* d = x_lds + xf_l[XF ? i : 0];
                     const float4 v = xst[XF ? i : 0];
+                    d[0] = v.x; d[PLANE_X] = v.y; d[2 * PLANE_X] = v.z; d[3 * PLANE_X] = v.w;
+                }
+        } else if (RES == NGAN_RESAMPLE_UP2) {
+#pragma unroll
+            for (int i = 0; i < NXP; ++i)
+                if (tid + i * NT < NPI) st4(patch + (tid + i * NT) * 4, xst[RES == NGAN_RESAMPLE_UP2 ? i : 0]);
+            __syncthreads();
+            int tt = tile;
+            const int txi = tt % a.tiles_x; tt /= a.tiles_x;
+            const int y0 = (tt % a.tiles_y) * TH, x0 = txi * TW;
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                if (x_r[i] > -1000) {
+                    // output row Y odd -> taps (i, i + 1) with weights (.75, .25); even -> (i - 1, i) with (.25, .75); the tile origin is
+                    // even, so parity, weights and the patch cell ((r + 1) >> 1, (c + 1) >> 1) depend on the slot only
+                    const float wy0 = (x_r[i] & 1) ? 0.75f : 0.25f, wx0 = (x_c[i] & 1) ? 0.75f : 0.25f;
+                    const float* r0 = patch + (((x_r[i] + 1) >> 1) * PW + ((x_c[i] + 1) >> 1)) * CI_S + (tid % Q) * 4;
+                    // (a packed-math (v_pk_fma) version of this blend needs aligned register pairs for 6 - 11 slots' weights, which the
+                    // compiler keeps live across the tile loop: 53 spilled registers, 230 -> 393 us.  Scalar fp32 it is.)
+                    const float4 top = f4fma(ld4(r0 + CI_S), 1.0f - wx0, f4scale(ld4(r0), wx0));
+                    const float4 bot = f4fma(ld4(r0 + PW * CI_S + CI_S), 1.0f - wx0, f4scale(ld4(r0 + PW * CI_S), wx0));
+                    float4 v = f4fma(bot, 1.0f - wy0, f4scale(top, wy0));
+                    const bool ok = (unsigned)(y0 + x_r[i]) < (unsigned)a.H && (unsigned)(x0 + x_c[i]) < (unsigned)a.W;   // conv padding
+                    v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+                    float* d = x_lds + x_l[i];
                     d[0] = v.x; d[PLANE_X] = v.y; d[2 * PLANE_X] = v.z; d[3 * PLANE_X] = v.w;
                 }
         } else {
