@@ -38,6 +38,35 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     packed[idx] = v * scale;
 }
 
+// Winograd F(2x2, 3x3) packing ("precision code 4", fp32): U = G g G^T per (cout, cin) pair, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
+// times scale.  Layout [position u*4 + v][n-tile mt][k-group g][lane][4] with the lane convention of pack_weights_kernel.
+__device__ __forceinline__ float wino_weight(const float* __restrict__ w, int Cout, int Cin, int mode, float scale, long idx) {
+    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    const int G = K / 16, MT = N / 16;
+    const int i = idx & 3, lane = (idx >> 2) & 63;
+    long r = idx >> 8;
+    const int g = r % G; r /= G;
+    const int mt = r % MT;
+    const int pos = r / MT, u = pos >> 2, v = pos & 3;
+    const int n = mt * 16 + (lane & 15), k = g * 16 + 4 * (lane >> 4) + i;
+    const float* src = mode == 0 ? w + ((long)n * Cin + k) * 9 : w + ((long)k * Cin + n) * 9;      // mode 1: taps flipped below
+    float gm[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) gm[t / 3][t % 3] = src[mode == 0 ? t : 8 - t];
+    // row u of G applied to the rows of g, then row v of G to the columns
+    float row[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        row[c] = u == 0 ? gm[0][c] : u == 3 ? gm[2][c] : 0.5f * (gm[0][c] + (u == 1 ? gm[1][c] : -gm[1][c]) + gm[2][c]);
+    const float val = v == 0 ? row[0] : v == 3 ? row[2] : 0.5f * (row[0] + (v == 1 ? row[1] : -row[1]) + row[2]);
+    return val * scale;
+}
+
+__global__ void pack_weights_wino_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int mode, float scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 16L * Cin * Cout) packed[idx] = wino_weight(w, Cout, Cin, mode, scale, idx);
+}
+
 // Split-bf16 ("bf16x3") packing for v_mfma_f32_16x16x32_bf16: every weight w*scale is written as hi = bf16(w) and
 // lo = bf16(w - hi).  Layout [step][n-tile mt][part hi/lo][lane][8]; lane l holds n = 16*mt + (l & 15) and
 // k = 8*(l >> 4) + j.  K = 16: a step is a PAIR of taps (k < 16 -> tap 2*step, k >= 16 -> tap 2*step + 1; the 10th
@@ -826,14 +855,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
-__global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_tile_kernel(ConvArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, PREC == 2 ? 2 : (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_tile_kernel(ConvArgs a, int n_tiles) {
+    // PREC: 0 exact fp32 (direct), 1 split bf16, 2 exact fp32 by Winograd F(2x2, 3x3) (16 -> 16 only; see the MFMA section)
+    constexpr bool BF = PREC == 1, WINO = PREC == 2;
+    static_assert(!WINO || (MTW == 1 && KG == 1), "the Winograd form is built for the 16 -> 16 layers");
 #ifdef NGAN_CLOCK_PROBE
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int THc = persist_tile_h(MTW, KG, 0), PGW = THc / 2, RPW = THc / 4;
     constexpr int HH_ = THc + 2, LP = 40;
     constexpr int NSTEP = KG == 1 ? 5 : 9;
-    constexpr int W_ELEMS = PREC ? NSTEP * MTW * 2 * 256 : 9 * KG * MTW * 256, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int W_ELEMS = BF ? NSTEP * MTW * 2 * 256 : (WINO ? 16 * 256 : 9 * KG * MTW * 256), PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
     constexpr int LPG = HH_ / 2;                 // interior loads per 16-channel group: HH_ rows x 32 columns x 4 quads / 256 threads
     constexpr int NL = KG * LPG, NST = NL + 1;   // + one load for the two halo columns
     constexpr int N_HALO = KG * 2 * HH_ * 4;     // its active lanes: (group, side, row, quad)
@@ -854,7 +886,13 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
     const int t_end = run.t_end;
 
     auto lds_slot = [&](int g, int c4, int ty, int tx) {
-        return PREC ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx) : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+        if (WINO) {
+            // even and odd columns in separate halves of a row (a lane reads columns 2p + b): position p + const, the same
+            // conflict-free pattern as the direct form's p + dx
+            const int pos = (tx >> 1) + (tx & 1) * (LP / 2);
+            return (ty * LP + pos) * 16 + ((c4 ^ (((pos >> 2) & 1) << 1)) << 2);
+        }
+        return BF ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx) : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
     };
     // ---- tile-invariant staging constants: byte offset from the halo origin (y0 - 1, x0 - 1), LDS float index ----
     unsigned s_voff[NST];
@@ -878,8 +916,14 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
     int rd[3];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) rd[dx] = (p + dx) * 16 + ((q ^ ((((p + dx) >> 2) & 1) << 1)) << 2);
-    int rs[PREC ? NSTEP : 1];
-    if (PREC) {
+    int wrd[4];                                    // Winograd: LDS float index of column 2p + b of a tile row, channel quad q
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int pos = p + (b >> 1) + (b & 1) * (LP / 2);
+        wrd[b] = pos * 16 + ((q ^ (((pos >> 2) & 1) << 1)) << 2);
+    }
+    int rs[BF ? NSTEP : 1];
+    if (BF) {
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
             int tap = KG == 1 ? 2 * st + (q >> 1) : st;
@@ -895,12 +939,14 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
     unsigned e_voff[PGW];
 #pragma unroll
     for (int pg = 0; pg < PGW; ++pg) {
-        const int row = wave * RPW + (pg >> 1), col = (pg & 1) * 16 + p;
+        // direct forms: pixel group = 16 consecutive pixels of a row; Winograd: pixel (a, b) of this lane's 2x2 output tile
+        const int row = WINO ? 2 * wave + (pg >> 1) : wave * RPW + (pg >> 1), col = WINO ? 2 * p + (pg & 1) : (pg & 1) * 16 + p;
         e_voff[pg] = (unsigned)((((OS * row) * Wo + OS * col) * N + q * 4) * 4);
     }
     constexpr int NSHIFT = MTW == 1 ? 4 : 5;       // pixel index * 4 bytes = (e_voff - 16 q) / N
     unsigned t_voff = 0;                           // ToImage: lane group q finishes pixel group q
-    if (EPI == EPI_TO_IMAGE) t_voff = (unsigned)(((wave * RPW + (q >> 1)) * a.W + (q & 1) * 16 + p) * 4);
+    if (EPI == EPI_TO_IMAGE) t_voff = WINO ? (unsigned)(((2 * wave + (q >> 1)) * a.W + 2 * p + (q & 1)) * 4)
+                                           : (unsigned)(((wave * RPW + (q >> 1)) * a.W + (q & 1) * 16 + p) * 4);
 
     auto decode = [&](int tt, int& b, int& y0, int& x0) {
         const int txi = tt % a.tiles_x; tt /= a.tiles_x;
@@ -965,11 +1011,11 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
 #endif
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            if (PREC) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
+            if (BF) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
             else st4(&tile[s_lds[i]], stg[i]);
         }
         if (tid < N_HALO) {
-            if (PREC) st_split<KG, PLANE>(tile, s_lds[NL], stg[NL]);
+            if (BF) st_split<KG, PLANE>(tile, s_lds[NL], stg[NL]);
             else st4(&tile[s_lds[NL]], stg[NL]);
         }
 #if !(defined(NGAN_EXP) && (NGAN_EXP & 16))
@@ -1020,7 +1066,50 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         for (int pg = 0; pg < PGW; ++pg)
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = bvec[mt];       // the bias: C operand of the first MFMA
-        if (PREC) {
+        if (WINO) {
+            // Winograd F(2x2, 3x3) (Lavin & Gray): Y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile and channel pair, the
+            // element-wise product summed over input channels = 16 small GEMMs (one per position (u, v) of the 4x4 transformed
+            // tile), 64 v_mfma_f32_16x16x4_f32 per wave and 64 output pixels instead of 144.  Wave = one row of 16 output tiles;
+            // lane (p, q) owns tile p and, as a B operand, input channels 4q..4q+3 (component s feeds MFMA s, as in the direct
+            // form), as a D operand output channels 4q..4q+3.  Both transforms are therefore lane-local: B^T d B on the 4x4 input
+            // patch it reads itself (16 ds_read_b128), A^T M A on its own accumulators.  G g G^T is done by the packing kernel.
+            //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]      A^T = [1 1 1 0; 0 1 -1 -1]
+            f32x4 bd[4][4];                          // B^T d: rows transformed, columns still in pixel space
+            {
+                const float* trow = tile + (2 * wave) * (LP * 16);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(trow + 0 * LP * 16 + wrd[b]), d1 = *reinterpret_cast<const f32x4*>(trow + 1 * LP * 16 + wrd[b]);
+                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(trow + 2 * LP * 16 + wrd[b]), d3 = *reinterpret_cast<const f32x4*>(trow + 3 * LP * 16 + wrd[b]);
+                    bd[0][b] = d0 - d2; bd[1][b] = d1 + d2; bd[2][b] = d2 - d1; bd[3][b] = d1 - d3;
+                }
+            }
+            f32x4 ta[2][4];                          // A^T M: output rows, columns still in transform space
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                f32x4 m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[u] = (u == 1 && v == 1) ? bvec[0] : (f32x4){0.f, 0.f, 0.f, 0.f};   // A^T e11 A = all ones: the bias
+                f32x4 vv[4];                         // (B^T d B)[u][v]
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    vv[u] = v == 0 ? bd[u][0] - bd[u][2] : v == 1 ? bd[u][1] + bd[u][2] : v == 2 ? bd[u][2] - bd[u][1] : bd[u][1] - bd[u][3];
+                f32x4 uu[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) uu[u] = *reinterpret_cast<const f32x4*>(&wl[(u * 4 + v) * 256 + lane * 4]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) m[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[u][i], vv[u][i], m[u], 0, 0, 0);
+                ta[0][v] = m[0] + m[1] + m[2];
+                ta[1][v] = m[1] - m[2] - m[3];
+            }
+#pragma unroll
+            for (int ar = 0; ar < 2; ++ar) {
+                acc[ar * 2 + 0][0] = ta[ar][0] + ta[ar][1] + ta[ar][2];
+                acc[ar * 2 + 1][0] = ta[ar][1] - ta[ar][2] - ta[ar][3];
+            }
+        } else if (BF) {
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 bf16x8 xh[PGW], xl[PGW];
@@ -2299,6 +2388,7 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackEntry* __restr
     const long idx = gidx - e.first;
     const int Cout = e.cout, Cin = e.cin, mode = e.mode;
     if (e.precision == 3) { pack_up2f_element(e.src, e.dst, Cout, Cin, e.scale, idx); return; }
+    if (e.precision == 4) { e.dst[idx] = wino_weight(e.src, Cout, Cin, mode, e.scale, idx); return; }
     const int Kreal = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
     const int K = e.precision == 2 ? 32 : Kreal;
     if (e.precision == 0) {
@@ -2337,6 +2427,7 @@ static long bf16x3_elements(int K, int N) {
 extern "C" long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int precision) {
     if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
     if (precision == 0) return 9L * Cin * Cout;
+    if (precision == 4) return 16L * Cin * Cout;
     const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
     if (precision == 2) return K == 16 ? bf16x3_elements(32, N) : 0;      // K = 16 padded to 32 (mid kernel)
     if (precision == 3) return mode == 0 && bf16x3_elements(K, N) ? 4 * bf16x3_elements(K, N) + 9L * K * N : 0;   // folded bilinear
@@ -2353,6 +2444,7 @@ extern "C" int ngan_conv3x3_pack_many(const void* table, int n_entries, long tot
 extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
     if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
     if (precision == 0) return 9L * Cin * Cout;
+    if (precision == 4) return 16L * Cin * Cout;
     if (precision == 2) {
         const long p0 = Cin == 16 ? bf16x3_elements(32, Cout) : 0, p1 = Cout == 16 ? bf16x3_elements(32, Cin) : 0;
         return ((p0 > p1 ? p0 : p1) + 1) / 2;
@@ -2362,8 +2454,18 @@ extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
     return ((e0 > e1 ? e0 : e1) + 1) / 2;
 }
 
+// exact-fp32 16 -> 16 layers on large images whose width is a multiple of the tile: Winograd F(2x2, 3x3) form of conv3x3_tile_kernel
+// (NGAN_WINOGRAD=0: direct form, A/B switch)
+static bool wino_eligible(int B, int H, int W, int K, int N, int resample) {
+    static const bool on = [] { const char* e = getenv("NGAN_WINOGRAD"); return !(e && e[0] == '0'); }();
+    static const bool tile_off = getenv("NGAN_TILE_KERNEL") && getenv("NGAN_TILE_KERNEL")[0] == '0';
+    return on && !tile_off && K == 16 && N == 16 && resample == NGAN_RESAMPLE_NONE && W % 32 == 0 && persist_eligible(B, H, W, K, N, resample);
+}
+
 extern "C" int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision) {
-    if (precision != 1 || B <= 0 || H <= 0 || W <= 0) return 0;
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (precision == 0) return wino_eligible(B, H, W, K, N, resample) ? 4 : 0;
+    if (precision != 1) return 0;
     if (up2f_eligible(B, H, W, K, N, resample)) return 3;
     if (persist_eligible(B, H, W, K, N, resample)) return 1;
     if (ngan::conv3x3_mid_eligible(B, H, W, K, N)) return 1;
@@ -2378,7 +2480,12 @@ extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int
     NGAN_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_pack_weights: Cin=%d, Cout=%d must be positive multiples of 16", Cin, Cout);
     NGAN_REQUIRE(mode == 0 || mode == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: mode %d", mode);
-    NGAN_REQUIRE(precision >= 0 && precision <= 3, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
+    NGAN_REQUIRE(precision >= 0 && precision <= 4, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
+    if (precision == 4) {
+        hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(ngan::ceil_div(16L * Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream,
+                           w_oihw, packed, Cout, Cin, mode, scale);
+        return ngan::launch_status("ngan_conv3x3_pack_weights(winograd)");
+    }
     if (precision == 3) {
         const long tot = ngan_conv3x3_pack_elements(Cout, Cin, mode, 3);
         NGAN_REQUIRE(tot > 0, NGAN_ERR_SHAPE, "conv3x3_pack_weights: precision 3 (folded bilinear) needs mode 0 and K = 16 or a multiple of 32");
@@ -2424,7 +2531,8 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
                                    float slope, float eps, int precision, int flags, void* stream) {
     NGAN_REQUIRE(x && packed && (y || epilogue == EPI_TO_IMAGE), NGAN_ERR_ARG, "conv3x3_fwd: null pointer");
     NGAN_REQUIRE((flags & ~NGAN_CONV_SKIP_BORDER) == 0, NGAN_ERR_ARG, "conv3x3_fwd: unknown flags 0x%x", flags);
-    NGAN_REQUIRE(precision == 0 || precision == ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, 1), NGAN_ERR_ARG,
+    NGAN_REQUIRE(precision == 0 || (precision == 4 && ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, 0) == 4) ||
+                 (precision != 4 && precision == ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, 1)), NGAN_ERR_ARG,
                  "conv3x3_fwd: precision %d is not available for this shape (ask ngan_conv3x3_uses_bf16x3)", precision);
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_fwd: bad dims B=%d H=%d W=%d", B, H, W);
     NGAN_REQUIRE(K > 0 && K % 16 == 0, NGAN_ERR_SHAPE, "conv3x3_fwd: K=%d must be a positive multiple of 16", K);
@@ -2453,6 +2561,12 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
                                    : (epilogue ? launch_up2f<2, EPI_LRELU_PN>(a, s) : launch_up2f<2, EPI_NONE>(a, s));
             if (st || (flags & NGAN_CONV_SKIP_BORDER)) return st;      // the caller launches ngan_conv3x3_up2_border itself
             return dispatch_up2_border(a, epilogue, s);
+        }
+        if (precision == 4) {      // Winograd form of the tile kernel (16 -> 16, plain input: checked by the precision test above)
+            if (epilogue == EPI_PN_BWD) return out_mode == 1 ? launch_tile<1, 1, EPI_PN_BWD, 1, 2>(a, s) : launch_tile<1, 1, EPI_PN_BWD, 0, 2>(a, s);
+            if (epilogue == EPI_TO_IMAGE) return launch_tile<1, 1, EPI_TO_IMAGE, 0, 2>(a, s);
+            if (out_mode == 1) return launch_tile<1, 1, 0, 1, 2>(a, s);
+            return epilogue ? launch_tile<1, 1, 1, 0, 2>(a, s) : launch_tile<1, 1, 0, 0, 2>(a, s);
         }
         if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, precision, s)
                                     : dispatch_persist<1, 2>(a, resample, epilogue, out_mode, precision, s);
@@ -2505,7 +2619,7 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     else if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0) {
         if ((out_mode || resample == 0) && W % 32 == 0)
             snprintf(buf, len, "conv3x3_tile_kernel<%d, %d, %d, %d, %d>", N / 16, K / 16, (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue,
-                     out_mode, precision);
+                     out_mode, precision == 4 ? 2 : precision);
         else
             snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
                      (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision);

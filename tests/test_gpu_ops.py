@@ -502,6 +502,9 @@ MANY_TILE_CASES = [
     # B, H, W, K, N, epilogue (0 plain, 1 LeakyReLU -> PixelNorm), pool-adjoint store: several tiles per persistent workgroup
     (32, 64, 64, 32, 32, 1, 0), (8, 256, 256, 16, 32, 1, 0), (32, 128, 128, 16, 16, 1, 0), (16, 64, 64, 32, 16, 0, 1),
     (4, 512, 512, 16, 16, 0, 0),
+    # 16 -> 16 in exact fp32 runs the Winograd F(2x2, 3x3) form of the tile kernel (precision code 4): pool-adjoint store, and an image
+    # height that is not a multiple of the 8-row tile (rows past the image belong to no one: dropped by the per-image descriptor)
+    (8, 128, 128, 16, 16, 0, 1), (6, 100, 128, 16, 16, 1, 0),
 ]
 
 
