@@ -411,8 +411,25 @@ constexpr int persist_tile_h(int MTW, int KG, int RES) { return (MTW * KG == 4 |
 __device__ unsigned long long g_clock_stamps[4 * 8192];
 #endif
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct f32p { f32x2 l, h; };                         // four floats as two register pairs (packed fp32 math)
+__device__ __forceinline__ f32p operator+(f32p a, f32p b) { return {a.l + b.l, a.h + b.h}; }
+// a - b as fma(b, -1, a): exact, and v_pk_fma_f32 exists where a packed subtraction does not (a v2f32 fsub is scalarised)
+// (-1 comes from a register the optimiser cannot see through, or it folds the fma back into the subtraction)
+__device__ __forceinline__ f32x2 opaque_minus_one() {
+    f32x2 m1 = {-1.0f, -1.0f};
+    asm("" : "+v"(m1));
+    return m1;
+}
+__device__ __forceinline__ f32p psub(f32p a, f32p b, f32x2 m1) { return {__builtin_elementwise_fma(b.l, m1, a.l), __builtin_elementwise_fma(b.h, m1, a.h)}; }
+__device__ __forceinline__ f32p pk2(f32x4 v) { return {(f32x2){v[0], v[1]}, (f32x2){v[2], v[3]}}; }
+__device__ __forceinline__ f32x4 unpk2(f32p v) { return (f32x4){v.l[0], v.l[1], v.h[0], v.h[1]}; }
+
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
-__global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, PREC == 2 ? 2 : (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
+    // PREC: 0 exact fp32 (direct), 1 split bf16, 2 exact fp32 by Winograd F(2x2, 3x3) (16 -> 16; the MFMA section of conv3x3_tile_kernel)
+    constexpr bool BF = PREC == 1, WINO = PREC == 2;
+    static_assert(!WINO || (MTW == 1 && KG == 1), "the Winograd form is built for the 16 -> 16 layers");
 #ifdef NGAN_CLOCK_PROBE
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
     constexpr int TWc = 32, HH_ = THc + 2, HW_ = TWc + 2, NPIX = HH_ * HW_, LP = 40;
     constexpr int PH = THc / 2 + 2, PW = TWc / 2 + 2, NPP = PH * PW;
     constexpr int NSTEP = KG == 1 ? 5 : 9;   // bf16x3: K = 32 contraction steps per tile
-    constexpr int W_ELEMS = PREC ? NSTEP * MTW * 2 * 256 : 9 * KG * MTW * 256, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int W_ELEMS = BF ? NSTEP * MTW * 2 * 256 : (WINO ? 16 * 256 : 9 * KG * MTW * 256), PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
     constexpr int PATCH_ELEMS = RES == NGAN_RESAMPLE_UP2 ? KG * NPP * 16 : 0;
     constexpr int N_SRC = RES == NGAN_RESAMPLE_UP2 ? KG * NPP * 4 : KG * NPIX * 4;   // float4 loads per tile
     constexpr int NST = (N_SRC + 255) / 256;
@@ -445,6 +462,22 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
     // ---- tile-invariant per-thread staging descriptors (all index arithmetic happens once, here) ----
     // source pixel offset from the tile origin (dy in the high half, dx in the low half of one register: the kernel runs at its
     // register cap, and the ticket of the dynamic tile schedule must stay in a register for a whole tile), channel, LDS float index
+    auto f32_or_bf16_slot = [&](int g, int c4, int ty, int tx) {
+        if (WINO) {      // even / odd columns in separate halves of a row: conv3x3_tile_kernel
+            const int pos = (tx >> 1) + (tx & 1) * (LP / 2);
+            return (ty * LP + pos) * 16 + ((c4 ^ (((pos >> 2) & 1) << 1)) << 2);
+        }
+        return BF ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx) : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+    };
+    // pixel group pg of a wave: 16 consecutive pixels of a row (direct forms) / pixel (pg >> 1, pg & 1) of this lane's 2x2 tile (Winograd)
+    auto pg_row = [&](int pg) { return WINO ? 2 * wave + (pg >> 1) : wave * RPW + (pg >> 1); };
+    auto pg_col = [&](int pg) { return WINO ? 2 * p + (pg & 1) : (pg & 1) * 16 + p; };
+    int wrd[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int pos = p + (b >> 1) + (b & 1) * (LP / 2);
+        wrd[b] = pos * 16 + ((q ^ (((pos >> 2) & 1) << 1)) << 2);
+    }
     int s_dyx[NST], s_ch[NST], s_lds[NST];
     auto dy_of = [](int v) { return v >> 16; };
     auto dx_of = [](int v) { return (int)(short)(v & 0xffff); };
@@ -460,8 +493,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             const int pix = (e >> 2) % NPIX, g = (e >> 2) / NPIX;
             const int ty = pix / HW_, tx = pix % HW_;
             s_dyx[i] = ((ty - 1) << 16) | ((tx - 1) & 0xffff); s_ch[i] = g * 16 + c4 * 4;
-            s_lds[i] = PREC ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx)
-                            : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+            s_lds[i] = f32_or_bf16_slot(g, c4, ty, tx);
         }
     }
     // expansion descriptors (bilinear): destination LDS index, the 4 patch taps and whether the item exists
@@ -474,8 +506,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             const int c4 = e & 3, pix = (e >> 2) % NPIX, g = (e >> 2) / NPIX;
             const int ty = pix / HW_, tx = pix % HW_;
             x_ty[i] = e < KG * NPIX * 4 ? ty : -100; x_tx[i] = tx;
-            x_dst[i] = PREC ? bf16_slot<KG, PLANE, LP>(g, c4, ty, tx)
-                            : g * PLANE + (ty * LP + tx) * 16 + ((c4 ^ (((tx >> 2) & 1) << 1)) << 2);
+            x_dst[i] = f32_or_bf16_slot(g, c4, ty, tx);
             // high-res (ty-1, tx-1) relative to an even tile origin: odd offsets are "even" output rows (2i): taps (i-1, i)
             // patch row index = low-res row - (y0/2 - 1); for offset d = ty-1: even d -> rows d/2, d/2+1 ; odd d -> (d+1)/2, (d+1)/2+1 ... see below
             const int dy = ty - 1, dx = tx - 1;   // in [-1, 8] / [-1, 32]
@@ -488,8 +519,8 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) rd[dx] = (p + dx) * 16 + ((q ^ ((((p + dx) >> 2) & 1) << 1)) << 2);
     // bf16x3: per contraction step, this lane's offset of the hi fragment (lo = same ^ 8 floats for K = 16, + PLANE for K = 32)
-    int rs[PREC ? NSTEP : 1];
-    if (PREC) {
+    int rs[BF ? NSTEP : 1];
+    if (BF) {
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
             int tap = KG == 1 ? 2 * st + (q >> 1) : st;
@@ -578,7 +609,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
                     float4 bot = f4fma(ld4(r0 + PW * 16 + 16), 1.0f - wx0, f4scale(ld4(r0 + PW * 16), wx0));
                     v = f4fma(bot, 1.0f - wy0, f4scale(top, wy0));
                 }
-                if (PREC) st_split<KG, PLANE>(tile, x_dst[i], v);
+                if (BF) st_split<KG, PLANE>(tile, x_dst[i], v);
                 else st4(&tile[x_dst[i]], v);
             }
         } else {
@@ -589,7 +620,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
 #else
                 if (tid + i * 256 < N_SRC) {
 #endif
-                    if (PREC) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
+                    if (BF) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
                     else st4(&tile[s_lds[i]], stg[i]);
                 }
         }
@@ -607,7 +638,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
             const long img0 = (long)b * a.H * a.W;
 #pragma unroll
             for (int pg = 0; pg < PGW; ++pg) {
-                const int gy = y0 + wave * RPW + (pg >> 1), gx = x0 + (pg & 1) * 16 + p;
+                const int gy = y0 + pg_row(pg), gx = x0 + pg_col(pg);
                 const bool valid = gy < a.H && gx < a.W;
                 const long pix = img0 + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
 #pragma unroll
@@ -621,7 +652,46 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         for (int pg = 0; pg < PGW; ++pg)
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) acc[pg][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (PREC) {
+        if (WINO) {
+            // Winograd F(2x2, 3x3): the section of conv3x3_tile_kernel (documented there); the bias is added by this kernel's epilogue
+            const f32x2 m1 = opaque_minus_one();
+            f32p bd[4][4];
+            {
+                const float* trow = tile + (2 * wave) * (LP * 16);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32p d0 = pk2(*reinterpret_cast<const f32x4*>(trow + 0 * LP * 16 + wrd[b])), d1 = pk2(*reinterpret_cast<const f32x4*>(trow + 1 * LP * 16 + wrd[b]));
+                    const f32p d2 = pk2(*reinterpret_cast<const f32x4*>(trow + 2 * LP * 16 + wrd[b])), d3 = pk2(*reinterpret_cast<const f32x4*>(trow + 3 * LP * 16 + wrd[b]));
+                    bd[0][b] = psub(d0, d2, m1); bd[1][b] = d1 + d2; bd[2][b] = psub(d2, d1, m1); bd[3][b] = psub(d1, d3, m1);
+                }
+            }
+            f32p ta[2][4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                f32x4 m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32p vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    vv[u] = v == 0 ? psub(bd[u][0], bd[u][2], m1) : v == 1 ? bd[u][1] + bd[u][2] : v == 2 ? psub(bd[u][2], bd[u][1], m1) : psub(bd[u][1], bd[u][3], m1);
+                f32x4 uu[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) uu[u] = *reinterpret_cast<const f32x4*>(&wl[(u * 4 + v) * 256 + lane * 4]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        m[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[u][i], i < 2 ? vv[u].l[i & 1] : vv[u].h[i & 1], m[u], 0, 0, 0);
+                ta[0][v] = pk2(m[0]) + pk2(m[1]) + pk2(m[2]);
+                ta[1][v] = psub(psub(pk2(m[1]), pk2(m[2]), m1), pk2(m[3]), m1);
+            }
+#pragma unroll
+            for (int ar = 0; ar < 2; ++ar) {
+                acc[ar * 2 + 0][0] = unpk2(ta[ar][0] + ta[ar][1] + ta[ar][2]);
+                acc[ar * 2 + 1][0] = unpk2(psub(psub(ta[ar][1], ta[ar][2], m1), ta[ar][3], m1));
+            }
+        } else if (BF) {
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 bf16x8 xh[PGW], xl[PGW];
@@ -699,7 +769,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         if (LATE) {
 #pragma unroll
             for (int pg = 0; pg < PGW; ++pg) {
-                const int gy = y0 + wave * RPW + (pg >> 1), gx = x0 + (pg & 1) * 16 + p;
+                const int gy = y0 + pg_row(pg), gx = x0 + pg_col(pg);
                 const bool valid = gy < a.H && gx < a.W;
                 const long pix = img + (long)(valid ? gy : 0) * a.W + (valid ? gx : 0);
 #pragma unroll
@@ -710,7 +780,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         }
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg) {
-            const int row = wave * RPW + (pg >> 1), col = (pg & 1) * 16 + p;
+            const int row = pg_row(pg), col = pg_col(pg);
             const int gy = y0 + row, gx = x0 + col;
             const bool valid = gy < a.H && gx < a.W;
             float4 v[MTW];
@@ -816,7 +886,7 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
         }
         if (EPI == EPI_TO_IMAGE) {
             // one tanh per lane instead of four: lane group q finishes pixel group q (same tanhf as the standalone ToImage kernel)
-            const int row = wave * RPW + (q >> 1), col = (q & 1) * 16 + p;
+            const int row = pg_row(q), col = pg_col(q);
             const int gy = y0 + row, gx = x0 + col;
             const float tv = tanhf(timg);
             if (q < PGW && gy < a.H && gx < a.W) a.aout[img + (long)gy * a.W + gx] = tv;
@@ -849,7 +919,6 @@ __global__ __launch_bounds__(256, (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void con
 // Same LDS image and MFMA order as conv3x3_persist_kernel; bit-identical to it without a bias (with one, the bias is added first
 // instead of last).
 // ---------------------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef NGAN_TILE_PRE
 #define NGAN_TILE_PRE 1
 #endif
@@ -1074,40 +1143,44 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : (MTW * KG == 1) ? (PREC ? 3 : 
             // form), as a D operand output channels 4q..4q+3.  Both transforms are therefore lane-local: B^T d B on the 4x4 input
             // patch it reads itself (16 ds_read_b128), A^T M A on its own accumulators.  G g G^T is done by the packing kernel.
             //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]      A^T = [1 1 1 0; 0 1 -1 -1]
-            f32x4 bd[4][4];                          // B^T d: rows transformed, columns still in pixel space
+            // (the transforms are written on register PAIRS: v_pk_add_f32 does two of the four channels per instruction -- the
+            // compiler left the float4 form as 184 scalar adds, and in this kernel a VALU instruction costs matrix time)
+            const f32x2 m1 = opaque_minus_one();
+            f32p bd[4][4];                           // B^T d: rows transformed, columns still in pixel space
             {
                 const float* trow = tile + (2 * wave) * (LP * 16);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(trow + 0 * LP * 16 + wrd[b]), d1 = *reinterpret_cast<const f32x4*>(trow + 1 * LP * 16 + wrd[b]);
-                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(trow + 2 * LP * 16 + wrd[b]), d3 = *reinterpret_cast<const f32x4*>(trow + 3 * LP * 16 + wrd[b]);
-                    bd[0][b] = d0 - d2; bd[1][b] = d1 + d2; bd[2][b] = d2 - d1; bd[3][b] = d1 - d3;
+                    const f32p d0 = pk2(*reinterpret_cast<const f32x4*>(trow + 0 * LP * 16 + wrd[b])), d1 = pk2(*reinterpret_cast<const f32x4*>(trow + 1 * LP * 16 + wrd[b]));
+                    const f32p d2 = pk2(*reinterpret_cast<const f32x4*>(trow + 2 * LP * 16 + wrd[b])), d3 = pk2(*reinterpret_cast<const f32x4*>(trow + 3 * LP * 16 + wrd[b]));
+                    bd[0][b] = psub(d0, d2, m1); bd[1][b] = d1 + d2; bd[2][b] = psub(d2, d1, m1); bd[3][b] = psub(d1, d3, m1);
                 }
             }
-            f32x4 ta[2][4];                          // A^T M: output rows, columns still in transform space
+            f32p ta[2][4];                           // A^T M: output rows, columns still in transform space
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 f32x4 m[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) m[u] = (u == 1 && v == 1) ? bvec[0] : (f32x4){0.f, 0.f, 0.f, 0.f};   // A^T e11 A = all ones: the bias
-                f32x4 vv[4];                         // (B^T d B)[u][v]
+                f32p vv[4];                          // (B^T d B)[u][v]
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    vv[u] = v == 0 ? bd[u][0] - bd[u][2] : v == 1 ? bd[u][1] + bd[u][2] : v == 2 ? bd[u][2] - bd[u][1] : bd[u][1] - bd[u][3];
+                    vv[u] = v == 0 ? psub(bd[u][0], bd[u][2], m1) : v == 1 ? bd[u][1] + bd[u][2] : v == 2 ? psub(bd[u][2], bd[u][1], m1) : psub(bd[u][1], bd[u][3], m1);
                 f32x4 uu[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) uu[u] = *reinterpret_cast<const f32x4*>(&wl[(u * 4 + v) * 256 + lane * 4]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) m[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[u][i], vv[u][i], m[u], 0, 0, 0);
-                ta[0][v] = m[0] + m[1] + m[2];
-                ta[1][v] = m[1] - m[2] - m[3];
+                    for (int u = 0; u < 4; ++u)
+                        m[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[u][i], i < 2 ? vv[u].l[i & 1] : vv[u].h[i & 1], m[u], 0, 0, 0);
+                ta[0][v] = pk2(m[0]) + pk2(m[1]) + pk2(m[2]);
+                ta[1][v] = psub(psub(pk2(m[1]), pk2(m[2]), m1), pk2(m[3]), m1);
             }
 #pragma unroll
             for (int ar = 0; ar < 2; ++ar) {
-                acc[ar * 2 + 0][0] = ta[ar][0] + ta[ar][1] + ta[ar][2];
-                acc[ar * 2 + 1][0] = ta[ar][1] - ta[ar][2] - ta[ar][3];
+                acc[ar * 2 + 0][0] = unpk2(ta[ar][0] + ta[ar][1] + ta[ar][2]);
+                acc[ar * 2 + 1][0] = unpk2(psub(psub(ta[ar][1], ta[ar][2], m1), ta[ar][3], m1));
             }
         } else if (BF) {
 #pragma unroll
@@ -2454,12 +2527,12 @@ extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
     return ((e0 > e1 ? e0 : e1) + 1) / 2;
 }
 
-// exact-fp32 16 -> 16 layers on large images whose width is a multiple of the tile: Winograd F(2x2, 3x3) form of conv3x3_tile_kernel
-// (NGAN_WINOGRAD=0: direct form, A/B switch)
+// exact-fp32 16 -> 16 layers on large images (plain or bilinear input): Winograd F(2x2, 3x3) form of conv3x3_tile_kernel /
+// conv3x3_persist_kernel (NGAN_WINOGRAD=0: direct form, A/B switch)
 static bool wino_eligible(int B, int H, int W, int K, int N, int resample) {
     static const bool on = [] { const char* e = getenv("NGAN_WINOGRAD"); return !(e && e[0] == '0'); }();
     static const bool tile_off = getenv("NGAN_TILE_KERNEL") && getenv("NGAN_TILE_KERNEL")[0] == '0';
-    return on && !tile_off && K == 16 && N == 16 && resample == NGAN_RESAMPLE_NONE && W % 32 == 0 && persist_eligible(B, H, W, K, N, resample);
+    return on && !tile_off && K == 16 && N == 16 && resample != NGAN_RESAMPLE_POOL2 && persist_eligible(B, H, W, K, N, resample);
 }
 
 extern "C" int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision) {
@@ -2562,12 +2635,8 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
             if (st || (flags & NGAN_CONV_SKIP_BORDER)) return st;      // the caller launches ngan_conv3x3_up2_border itself
             return dispatch_up2_border(a, epilogue, s);
         }
-        if (precision == 4) {      // Winograd form of the tile kernel (16 -> 16, plain input: checked by the precision test above)
-            if (epilogue == EPI_PN_BWD) return out_mode == 1 ? launch_tile<1, 1, EPI_PN_BWD, 1, 2>(a, s) : launch_tile<1, 1, EPI_PN_BWD, 0, 2>(a, s);
-            if (epilogue == EPI_TO_IMAGE) return launch_tile<1, 1, EPI_TO_IMAGE, 0, 2>(a, s);
-            if (out_mode == 1) return launch_tile<1, 1, 0, 1, 2>(a, s);
-            return epilogue ? launch_tile<1, 1, 1, 0, 2>(a, s) : launch_tile<1, 1, 0, 0, 2>(a, s);
-        }
+        if (precision == 4)        // Winograd form (16 -> 16: checked by the precision test above): template precision 2
+            return dispatch_persist2<1, 1, 2>(a, resample, epilogue, out_mode, s);
         if (N == 16) return K == 16 ? dispatch_persist<1, 1>(a, resample, epilogue, out_mode, precision, s)
                                     : dispatch_persist<1, 2>(a, resample, epilogue, out_mode, precision, s);
         return K == 16 ? dispatch_persist<2, 1>(a, resample, epilogue, out_mode, precision, s)
@@ -2622,7 +2691,7 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
                      out_mode, precision == 4 ? 2 : precision);
         else
             snprintf(buf, len, "conv3x3_persist_kernel<%d, %d, %d, %d, %d, %d>", N / 16, K / 16, out_mode ? 0 : resample,
-                     (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision);
+                     (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode, precision == 4 ? 2 : precision);
     }
     else if ((precision >= 1 || (mid_f32_enabled() && resample != NGAN_RESAMPLE_POOL2)) && ngan::conv3x3_mid_eligible(B, H, W, precision == 2 ? 32 : K, N))
         return ngan::conv3x3_mid_kernel_name(B, H, W, precision == 2 ? 32 : K, N, resample, epilogue, out_mode, precision, buf, len);
