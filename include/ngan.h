@@ -56,14 +56,20 @@ int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int 
  *   3 split-bf16 with the bilinear x2 of `resample` 2 folded into the weights (N = 16, K in {16, 32}, large images): `packed` then
  *     holds four 3x3 weight sets over the LOW-resolution input, one per output parity (py, px),
  *     W_eff[dr][dc] = sum_{ky,kx} W[ky][kx] * E[py][ky][dr] * E[px][kx][dc]  (E: the .25/.75 blend rows of upsample_bilinear2d,
- *     align_corners = False), followed by the scaled fp32 weights for the one-pixel border ring (mode 0 only). */
+ *     align_corners = False), followed by the scaled fp32 weights for the one-pixel border ring (mode 0 only);
+ *   4 exact fp32 by Winograd F(2x2, 3x3) (answered for a REQUESTED precision 0 on the 16 -> 16 layers of large images, plain or
+ *     bilinear input): `packed` holds the 16 transformed weight sets G g G^T (16 * Cin * Cout floats), the kernel transforms 4x4
+ *     input patches (B^T d B) and 2x2 output tiles (A^T M A) per lane and spends 64 instead of 144 v_mfma_f32_16x16x4_f32 per
+ *     64 pixels.  fp32 arithmetic throughout; its error against an fp64 convolution is no larger than the direct form's
+ *     (tools/wino_check.py: relative L2 1.5e-7 against 2.6e-7).  NGAN_WINOGRAD=0 in the environment answers 0 instead.
+ * (The function keeps its round-1 name; what it returns is the precision code for any requested precision.) */
 int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision);
 long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision);   /* size of `packed` in floats */
 
 /* Re-pack many weights with ONE launch (after an optimiser step).  `table` is a device array of n_entries records
  *   { const float* src; float* dst; int Cout, Cin, mode, precision; float scale; int pad; long first; }          (48 bytes)
  * where `first` is the running sum of ngan_conv3x3_pack_elements(...) over the preceding entries (the unit is one packed
- * element: a float for precision 0, a bf16 for precision 1 / 2, precision 3: bf16 for the four sets, then one per raw fp32
+ * element: a float for precision 0 / 4, a bf16 for precision 1 / 2, precision 3: bf16 for the four sets, then one per raw fp32
  * weight) and total_elements is the sum over all entries. */
 long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int precision);
 int ngan_conv3x3_pack_many(const void* table, int n_entries, long total_elements, void* stream);

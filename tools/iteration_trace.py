@@ -6,6 +6,7 @@ Adam launches: D step (ends with the critic's adam_kernel) + G step (ends with t
 """
 import csv
 import glob
+import os
 import re
 import sys
 
@@ -17,7 +18,7 @@ def short(name):
 
 
 def main(run_dir):
-    path = sorted(glob.glob(run_dir + "/*/*_kernel_trace.csv"))[0]
+    path = max(glob.glob(run_dir + "/*/*_kernel_trace.csv"), key=os.path.getmtime)       # the newest run in the directory
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
     adam = [i for i, n in enumerate(names) if n.startswith("adam_kernel")]
