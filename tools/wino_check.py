@@ -8,9 +8,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = [  # B, H, W, epilogue, out_mode, mode (0 forward weights, 1 input-gradient weights)
-    (2, 64, 64, 0, 0, 0), (2, 64, 64, 1, 0, 0), (3, 96, 96, 1, 0, 1), (1, 44, 64, 1, 0, 0), (2, 50, 32, 0, 0, 1), (4, 128, 128, 2, 0, 1),
-    (2, 64, 64, 0, 1, 1), (2, 64, 96, 2, 1, 1), (2, 256, 256, 3, 0, 0), (16, 256, 256, 1, 0, 0), (16, 256, 256, 0, 0, 1),
+SHAPES = [  # B, H, W, epilogue, out_mode, mode (0 forward weights, 1 input-gradient weights), resample (0 plain, 2 bilinear x2 on load)
+    (8, 128, 128, 0, 0, 0, 0), (8, 128, 128, 1, 0, 0, 0), (6, 100, 128, 1, 0, 1, 0), (1, 200, 328, 0, 0, 0, 0), (1, 200, 328, 1, 0, 1, 0),
+    (8, 128, 128, 2, 0, 1, 0), (8, 128, 128, 0, 1, 1, 0), (8, 128, 128, 2, 1, 1, 0), (2, 256, 256, 3, 0, 0, 0), (16, 256, 256, 1, 0, 0, 0),
+    (16, 256, 256, 0, 0, 1, 0), (2, 128, 256, 0, 0, 0, 2), (2, 136, 296, 1, 0, 0, 2),
 ]
 
 
@@ -19,11 +20,11 @@ def run(path):
     pkg = load_package()
     C, ops = pkg._C, pkg.ops
     outs = []
-    for (B, H, W, epi, om, mode) in SHAPES:
+    for (B, H, W, epi, om, mode, res) in SHAPES:
         torch.manual_seed(B + H + W + epi + om)
         K = N = 16
-        prec = C.conv3x3_uses_bf16x3(B, H, W, K, N, 0, 0)
-        x = torch.randn(B, H, W, K, device="cuda")
+        prec = C.conv3x3_uses_bf16x3(B, H, W, K, N, res, 0)
+        x = torch.randn(B, H // 2, W // 2, K, device="cuda") if res == 2 else torch.randn(B, H, W, K, device="cuda")
         w = torch.randn(N, K, 3, 3, device="cuda")
         oh, ow = (2 * H, 2 * W) if om else (H, W)
         ay = torch.randn(B, oh, ow, N, device="cuda") if epi == 2 else (torch.randn(N, device="cuda") if epi == 3 else None)
@@ -33,14 +34,17 @@ def run(path):
         packed = ops._packed(w, mode, 0.1, prec)
         y = torch.zeros(B, oh, ow, N, device="cuda")
         rn = torch.zeros(B, H, W, device="cuda")
-        C.call("ngan_conv3x3_fwd_ex", x, packed, bias, y, rn if epi in (1, 3) else None, ay, arn, aout, B, H, W, K, N, 0, epi, om, 0.2, 1e-8, prec, 0)
+        C.call("ngan_conv3x3_fwd_ex", x, packed, bias, y, rn if epi in (1, 3) else None, ay, arn, aout, B, H, W, K, N, res, epi, om, 0.2, 1e-8, prec, 0)
         torch.cuda.synchronize()
         ref = None
         if epi == 0 and om == 0:
             wd = w.double().cpu()
             if mode == 1:
                 wd = wd.flip(2, 3).transpose(0, 1)
-            ref = torch.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2) * 0.1, wd, bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+            xin = x.double().cpu().permute(0, 3, 1, 2)
+            if res == 2:
+                xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="bilinear", align_corners=False)
+            ref = torch.nn.functional.conv2d(xin * 0.1, wd, bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
         outs.append((prec, y.cpu(), rn.cpu(), aout.cpu() if aout is not None else None, ref))
     torch.save(outs, path)
 
