@@ -1894,8 +1894,16 @@ __global__ __launch_bounds__(256, (COT * CIT == 1) ? 4 : 2) void wgrad_kernel(Wg
 // ---------------------------------------------------------------------------------------------------------
 constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }      // smallest m >= n with m = 4 (mod 64)
 
-template <int COT, int CIT, int RES, int TW, int NW, int XF>
-__global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
+// WINO = 1 (16 x 16 slices, 8 x 32 tiles): the contraction in Winograd form, dW = G^T [ sum over 2x2 output tiles of (A dY A^T) . (B^T d B) ] G
+// -- the backward-filter counterpart of conv3x3_tile_kernel's F(2x2, 3x3).  A wave takes one row of 16 tiles; an MFMA contracts over
+// 4 tiles: lane (p, q) holds, for tile 4 ks + q, the transformed 2x2 output-gradient patch of output channel p (A operand) and the
+// transformed 4x4 input patch of input channel p (B operand), both computed by itself from its channel plane (2 + 8 ds_read_b64).
+// 16 accumulators (one per position of the 4x4 transformed tile) instead of 9 taps; 64 instead of 144 MFMAs per wave and tile.
+// The G^T . G back-transform is linear, so every workgroup applies it to its own partial sum before writing the slab: slab
+// format, slab reduction and bit-reproducibility are those of the direct form.
+template <int COT, int CIT, int RES, int TW, int NW, int XF, int WINO = 0>
+__global__ __launch_bounds__(NW * 64, WINO ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
+    static_assert(!WINO || (COT == 1 && CIT == 1 && TW == 32 && NW == 4), "Winograd weight gradient: 16 x 16 slices, 8 x 32 tiles, 4 waves");
     constexpr int NT = NW * 64;
     constexpr int TH = 256 / TW, HALO_H = TH + 2, NBLK = TW / 16;
     constexpr int CO_S = COT * 16, CI_S = CIT * 16;
@@ -1903,7 +1911,8 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
     constexpr int XP = TW + 4;                                                   // x row pitch (TW + 2 used), a multiple of 4
     constexpr int PLANE_G = pad_plane(TH * TW), PLANE_X = pad_plane(HALO_H * XP);
     constexpr int G_ELEMS = CO_S * PLANE_G, X_ELEMS = CI_S * PLANE_X;
-    constexpr int RED_ELEMS = NW * 9 * 64 * 4;
+    constexpr int NACC = WINO ? 16 : 9;
+    constexpr int RED_ELEMS = NW * NACC * 64 * 4;
     // bilinear input: the low-resolution source patch of the halo tile is loaded once (fp32, [py][px][CI_S]) and expanded LDS -> LDS,
     // as in wgrad_bf16x3_kernel: 2 global loads per thread instead of 24, and the tap / weight arithmetic is tile-invariant
     constexpr int PH = TH / 2 + 2, PW = TW / 2 + 2, NPP = PH * PW;
@@ -1964,9 +1973,9 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
         xf_bits = used ? ((side ? 2 : 1) | (r == 0 ? 4 : 0)) : 8;
     }
 
-    f32x4 acc[9];
+    f32x4 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NACC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 gst[NG], xst[XF ? NXF : (RES == NGAN_RESAMPLE_UP2 ? NXP : NX)];
     constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -2088,6 +2097,41 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
         __syncthreads();
         const int tn = tile + gridDim.x;
         if (tn < a.n_tiles) issue(tn);   // next tile's loads are in flight during the MFMAs
+        if (WINO) {
+            // this wave's tile row: output rows 2 wr, 2 wr + 1 = halo rows 2 wr .. 2 wr + 3.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] is used
+            // without the minus signs of its last row (one negation per element saved); the back-transform flips the sign of every
+            // position with u = 3 xor v = 3 instead.
+            const float* gp = ga - 4 * q + (2 * wr) * TW + 2 * q;          // ga = plane p + 4 q: back to the plane, then tile column q
+            const float* xp = xa - 4 * q + (2 * wr) * XP + 2 * q;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float d[4][4], gy[2][2];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float2 lo = *reinterpret_cast<const float2*>(xp + r4 * XP + 8 * ks), hi = *reinterpret_cast<const float2*>(xp + r4 * XP + 8 * ks + 2);
+                    d[r4][0] = lo.x; d[r4][1] = lo.y; d[r4][2] = hi.x; d[r4][3] = hi.y;
+                }
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const float2 v = *reinterpret_cast<const float2*>(gp + r2 * TW + 8 * ks);
+                    gy[r2][0] = v.x; gy[r2][1] = v.y;
+                }
+                float t[4][4], V[4][4], sg[4][2], M[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { t[0][c] = d[0][c] - d[2][c]; t[1][c] = d[1][c] + d[2][c]; t[2][c] = d[2][c] - d[1][c]; t[3][c] = d[1][c] - d[3][c]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { V[u][0] = t[u][0] - t[u][2]; V[u][1] = t[u][1] + t[u][2]; V[u][2] = t[u][2] - t[u][1]; V[u][3] = t[u][1] - t[u][3]; }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { sg[0][c] = gy[0][c]; sg[1][c] = gy[0][c] + gy[1][c]; sg[2][c] = gy[0][c] - gy[1][c]; sg[3][c] = gy[1][c]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { M[u][0] = sg[u][0]; M[u][1] = sg[u][0] + sg[u][1]; M[u][2] = sg[u][0] - sg[u][1]; M[u][3] = sg[u][1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        acc[u * 4 + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[u][v], V[u][v], acc[u * 4 + v], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wr * RPW + rr;
@@ -2116,10 +2160,42 @@ __global__ __launch_bounds__(NW * 64, (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(smem);
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-        red[(wave * 9 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    for (int t = 0; t < NACC; ++t)
+        red[(wave * NACC + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
     __syncthreads();
     float* slab = a.partial + ((long)blockIdx.x * gridDim.y + slice) * (9 * CO_S * CI_S);
+    if (WINO) {
+        // thread (l, u): row u of the summed 4x4 position tile of lane l (waves in fixed order), multiplied by G from the right:
+        // Z[u][j] = sum_v s_v dU[u][v] G[v][j],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  s = (1, 1, 1, -1) (see the MFMA section)
+        const int l = tid & 63, u = tid >> 6;
+        float4 du[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float4 sum = red[(0 * 16 + u * 4 + v) * 64 + l];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) sum = f4add(sum, red[(w * 16 + u * 4 + v) * 64 + l]);
+            du[v] = sum;
+        }
+        const float su = u == 3 ? -1.f : 1.f;
+        const float4 h12p = f4scale(f4add(du[1], du[2]), 0.5f), h12m = f4scale(f4add(du[1], f4scale(du[2], -1.f)), 0.5f);
+        const float4 z0 = f4scale(f4add(du[0], h12p), su), z1 = f4scale(h12m, su), z2 = f4scale(f4add(h12p, f4scale(du[3], -1.f)), su);
+        __syncthreads();                                     // every thread has read its part of `red`
+        red[(u * 3 + 0) * 64 + l] = z0; red[(u * 3 + 1) * 64 + l] = z1; red[(u * 3 + 2) * 64 + l] = z2;
+        __syncthreads();
+        // thread (l, i < 3): dW[i][j] = sum_u G^T[i][u] Z[u][j]
+        if (u < 3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 z_0 = red[(0 * 3 + j) * 64 + l], z_1 = red[(1 * 3 + j) * 64 + l], z_2 = red[(2 * 3 + j) * 64 + l], z_3 = red[(3 * 3 + j) * 64 + l];
+                const float4 p12 = f4scale(f4add(z_1, z_2), 0.5f), m12 = f4scale(f4add(z_1, f4scale(z_2, -1.f)), 0.5f);
+                const float4 v = u == 0 ? f4add(z_0, p12) : u == 1 ? m12 : f4add(p12, z_3);
+                const int ci_l = l & 15, co_l = 4 * (l >> 4);
+                float* op = slab + ((long)(u * 3 + j) * CO_S + co_l) * CI_S + ci_l;
+                op[0] = v.x; op[CI_S] = v.y; op[2 * CI_S] = v.z; op[3 * CI_S] = v.w;
+            }
+        }
+        return;
+    }
     for (int e = tid; e < WO * 9 * 64; e += NT) {
         const int l = e & 63, t = (e >> 6) % 9, o = (e >> 6) / 9;
         float4 v = red[(o * 9 + t) * 64 + l];               // wave index = wr*WO + wo
@@ -2417,6 +2493,16 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision,
     static const bool v1 = getenv("NGAN_WGRAD_V1") && getenv("NGAN_WGRAD_V1")[0] == '1';     // A/B switch: the first fp32 kernel
     if (!v1) {
         constexpr int NW = wgrad_f32_waves(COT, CIT);
+        static const bool wino = !(getenv("NGAN_WINOGRAD_WGRAD") && getenv("NGAN_WINOGRAD_WGRAD")[0] == '0');    // A/B switch
+        if constexpr (COT == 1 && CIT == 1) {
+            if (wino && p.tw == 32) {
+                if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_f32_kernel<1, 1, 0, 32, 4, 1, 1>), grid, dim3(256), 0, s, a);
+                else if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<1, 1, 0, 32, 4, 0, 1>), grid, dim3(256), 0, s, a);
+                else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<1, 1, 1, 32, 4, 0, 1>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((wgrad_f32_kernel<1, 1, 2, 32, 4, 0, 1>), grid, dim3(256), 0, s, a);
+                return ngan::launch_status("ngan_conv3x3_wgrad(f32, winograd)");
+            }
+        }
         if (p.tw == 32) {
             if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 1>), grid, dim3(NW * 64), 0, s, a);
             else if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 0>), grid, dim3(NW * 64), 0, s, a);
@@ -2715,8 +2801,11 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
                  "conv3x3_wgrad_kernel_name: bad shape");
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
     if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
-    else snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw, wgrad_f32_waves(p.co_s / 16, p.ci_s / 16),
-                  (resample == 0 && p.tw == 32 && W % 32 == 0) ? 1 : 0);
+    else {
+        const bool wino = !(getenv("NGAN_WINOGRAD_WGRAD") && getenv("NGAN_WINOGRAD_WGRAD")[0] == '0') && p.co_s == 16 && p.ci_s == 16 && p.tw == 32;
+        snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw,
+                 wgrad_f32_waves(p.co_s / 16, p.ci_s / 16), (resample == 0 && p.tw == 32 && W % 32 == 0) ? 1 : 0, wino ? 1 : 0);
+    }
     return NGAN_OK;
 }
 
