@@ -1902,7 +1902,7 @@ constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }      // 
 // The G^T . G back-transform is linear, so every workgroup applies it to its own partial sum before writing the slab: slab
 // format, slab reduction and bit-reproducibility are those of the direct form.
 template <int COT, int CIT, int RES, int TW, int NW, int XF, int WINO = 0>
-__global__ __launch_bounds__(NW * 64, WINO ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
+__global__ __launch_bounds__(NW * 64, (WINO && RES != 0) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
     static_assert(!WINO || (COT == 1 && CIT == 1 && TW == 32 && NW == 4), "Winograd weight gradient: 16 x 16 slices, 8 x 32 tiles, 4 waves");
     constexpr int NT = NW * 64;
     constexpr int TH = 256 / TW, HALO_H = TH + 2, NBLK = TW / 16;
@@ -1912,7 +1912,7 @@ __global__ __launch_bounds__(NW * 64, WINO ? 2 : (COT * CIT == 1) ? 3 : (COT * C
     constexpr int PLANE_G = pad_plane(TH * TW), PLANE_X = pad_plane(HALO_H * XP);
     constexpr int G_ELEMS = CO_S * PLANE_G, X_ELEMS = CI_S * PLANE_X;
     constexpr int NACC = WINO ? 16 : 9;
-    constexpr int RED_ELEMS = NW * NACC * 64 * 4;
+    constexpr int RED_ELEMS = NW * (WINO ? 8 : 9) * 64 * 4;      // (Winograd: the 16 positions cross the waves in two halves of 8)
     // bilinear input: the low-resolution source patch of the halo tile is loaded once (fp32, [py][px][CI_S]) and expanded LDS -> LDS,
     // as in wgrad_bf16x3_kernel: 2 global loads per thread instead of 24, and the tap / weight arithmetic is tile-invariant
     constexpr int PH = TH / 2 + 2, PW = TW / 2 + 2, NPP = PH * PW;
@@ -2159,22 +2159,36 @@ __global__ __launch_bounds__(NW * 64, WINO ? 2 : (COT * CIT == 1) ? 3 : (COT * C
     // ---- sum the WR row-waves of each sub-slice through LDS (fixed order), then write this block's slab ----
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(smem);
-#pragma unroll
-    for (int t = 0; t < NACC; ++t)
-        red[(wave * NACC + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-    __syncthreads();
     float* slab = a.partial + ((long)blockIdx.x * gridDim.y + slice) * (9 * CO_S * CI_S);
+    if (!WINO) {
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+            red[(wave * NACC + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        __syncthreads();
+    }
     if (WINO) {
         // thread (l, u): row u of the summed 4x4 position tile of lane l (waves in fixed order), multiplied by G from the right:
         // Z[u][j] = sum_v s_v dU[u][v] G[v][j],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  s = (1, 1, 1, -1) (see the MFMA section)
         const int l = tid & 63, u = tid >> 6;
-        float4 du[4];
+        float4 du[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            float4 sum = red[(0 * 16 + u * 4 + v) * 64 + l];
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
 #pragma unroll
-            for (int w = 1; w < 4; ++w) sum = f4add(sum, red[(w * 16 + u * 4 + v) * 64 + l]);
-            du[v] = sum;
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 v = acc[half * 8 + t];
+                red[(wave * 8 + t) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            __syncthreads();
+            if ((u >> 1) == half) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float4 sum = red[(0 * 8 + (u & 1) * 4 + v) * 64 + l];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) sum = f4add(sum, red[(w * 8 + (u & 1) * 4 + v) * 64 + l]);
+                    du[v] = sum;
+                }
+            }
         }
         const float su = u == 3 ? -1.f : 1.f;
         const float4 h12p = f4scale(f4add(du[1], du[2]), 0.5f), h12m = f4scale(f4add(du[1], f4scale(du[2], -1.f)), 0.5f);
