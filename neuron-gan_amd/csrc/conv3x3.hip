@@ -1896,7 +1896,7 @@ constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }      // 
 
 // WINO = 1 (16 x 16 slices, 8 x 32 tiles): the contraction in Winograd form, dW = G^T [ sum over 2x2 output tiles of (A dY A^T) . (B^T d B) ] G
 // -- the backward-filter counterpart of conv3x3_tile_kernel's F(2x2, 3x3).  A wave takes one row of 16 tiles; an MFMA contracts over
-// 4 tiles: lane (p, q) holds, for tile 4 ks + q, the transformed 2x2 output-gradient patch of output channel p (A operand) and the
+// 4 tiles: lane (p, q) holds, for tile 4 q + ks, the transformed 2x2 output-gradient patch of output channel p (A operand) and the
 // transformed 4x4 input patch of input channel p (B operand), both computed by itself from its channel plane (2 + 8 ds_read_b64).
 // 16 accumulators (one per position of the 4x4 transformed tile) instead of 9 taps; 64 instead of 144 MFMAs per wave and tile.
 // The G^T . G back-transform is linear, so every workgroup applies it to its own partial sum before writing the slab: slab
@@ -2101,35 +2101,47 @@ __global__ __launch_bounds__(NW * 64, (WINO && RES != 0) ? 2 : (COT * CIT == 1) 
             // this wave's tile row: output rows 2 wr, 2 wr + 1 = halo rows 2 wr .. 2 wr + 3.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] is used
             // without the minus signs of its last row (one negation per element saved); the back-transform flips the sign of every
             // position with u = 3 xor v = 3 instead.
-            const float* gp = ga - 4 * q + (2 * wr) * TW + 2 * q;          // ga = plane p + 4 q: back to the plane, then tile column q
-            const float* xp = xa - 4 * q + (2 * wr) * XP + 2 * q;
+            // lane (p, q) owns the four consecutive tiles 4 q .. 4 q + 3 of the row (K-step ks contracts tiles 4 q + ks over q): two tiles
+            // at a time are one 16-byte + one 8-byte read per input row and one 16-byte read per gradient row
+            const float* gp = ga - 4 * q + (2 * wr) * TW + 8 * q;          // ga = plane p + 4 q: back to the plane, then column 8 q
+            const float* xp = xa - 4 * q + (2 * wr) * XP + 8 * q;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                float d[4][4], gy[2][2];
+            for (int kp = 0; kp < 2; ++kp) {
+                float xr[4][6], gr[2][4];
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const float2 lo = *reinterpret_cast<const float2*>(xp + r4 * XP + 8 * ks), hi = *reinterpret_cast<const float2*>(xp + r4 * XP + 8 * ks + 2);
-                    d[r4][0] = lo.x; d[r4][1] = lo.y; d[r4][2] = hi.x; d[r4][3] = hi.y;
+                    const float4 lo = ld4(xp + r4 * XP + 4 * kp);
+                    const float2 hi = *reinterpret_cast<const float2*>(xp + r4 * XP + 4 * kp + 4);
+                    xr[r4][0] = lo.x; xr[r4][1] = lo.y; xr[r4][2] = lo.z; xr[r4][3] = lo.w; xr[r4][4] = hi.x; xr[r4][5] = hi.y;
                 }
 #pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2) {
-                    const float2 v = *reinterpret_cast<const float2*>(gp + r2 * TW + 8 * ks);
-                    gy[r2][0] = v.x; gy[r2][1] = v.y;
+                    const float4 v = ld4(gp + r2 * TW + 4 * kp);
+                    gr[r2][0] = v.x; gr[r2][1] = v.y; gr[r2][2] = v.z; gr[r2][3] = v.w;
                 }
-                float t[4][4], V[4][4], sg[4][2], M[4][4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { t[0][c] = d[0][c] - d[2][c]; t[1][c] = d[1][c] + d[2][c]; t[2][c] = d[2][c] - d[1][c]; t[3][c] = d[1][c] - d[3][c]; }
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    float t[4][4], V[4][4], sg[4][2], M[4][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { V[u][0] = t[u][0] - t[u][2]; V[u][1] = t[u][1] + t[u][2]; V[u][2] = t[u][2] - t[u][1]; V[u][3] = t[u][1] - t[u][3]; }
+                    for (int c = 0; c < 4; ++c) {
+                        const float d0 = xr[0][2 * t2 + c], d1 = xr[1][2 * t2 + c], d2 = xr[2][2 * t2 + c], d3 = xr[3][2 * t2 + c];
+                        t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
+                    }
 #pragma unroll
-                for (int c = 0; c < 2; ++c) { sg[0][c] = gy[0][c]; sg[1][c] = gy[0][c] + gy[1][c]; sg[2][c] = gy[0][c] - gy[1][c]; sg[3][c] = gy[1][c]; }
+                    for (int u = 0; u < 4; ++u) { V[u][0] = t[u][0] - t[u][2]; V[u][1] = t[u][1] + t[u][2]; V[u][2] = t[u][2] - t[u][1]; V[u][3] = t[u][1] - t[u][3]; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { M[u][0] = sg[u][0]; M[u][1] = sg[u][0] + sg[u][1]; M[u][2] = sg[u][0] - sg[u][1]; M[u][3] = sg[u][1]; }
+                    for (int c = 0; c < 2; ++c) {
+                        const float g0 = gr[0][2 * t2 + c], g1 = gr[1][2 * t2 + c];
+                        sg[0][c] = g0; sg[1][c] = g0 + g1; sg[2][c] = g0 - g1; sg[3][c] = g1;
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 4; ++u) { M[u][0] = sg[u][0]; M[u][1] = sg[u][0] + sg[u][1]; M[u][2] = sg[u][0] - sg[u][1]; M[u][3] = sg[u][1]; }
 #pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        acc[u * 4 + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[u][v], V[u][v], acc[u * 4 + v], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            acc[u * 4 + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[u][v], V[u][v], acc[u * 4 + v], 0, 0, 0);
+                }
             }
         } else
 #pragma unroll
