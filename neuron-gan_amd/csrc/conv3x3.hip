@@ -1902,8 +1902,8 @@ constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }      // 
 // The G^T . G back-transform is linear, so every workgroup applies it to its own partial sum before writing the slab: slab
 // format, slab reduction and bit-reproducibility are those of the direct form.
 template <int COT, int CIT, int RES, int TW, int NW, int XF, int WINO = 0>
-__global__ __launch_bounds__(NW * 64, (WINO && RES != 0) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
-    static_assert(!WINO || (COT == 1 && CIT == 1 && TW == 32 && NW == 4), "Winograd weight gradient: 16 x 16 slices, 8 x 32 tiles, 4 waves");
+__global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
+    static_assert(!WINO || TW == 32, "Winograd weight gradient: 8 x 32 tiles (a wave takes whole rows of 16 tiles)");
     constexpr int NT = NW * 64;
     constexpr int TH = 256 / TW, HALO_H = TH + 2, NBLK = TW / 16;
     constexpr int CO_S = COT * 16, CI_S = CIT * 16;
@@ -2103,8 +2103,10 @@ __global__ __launch_bounds__(NW * 64, (WINO && RES != 0) ? 2 : (COT * CIT == 1) 
             // position with u = 3 xor v = 3 instead.
             // lane (p, q) owns the four consecutive tiles 4 q .. 4 q + 3 of the row (K-step ks contracts tiles 4 q + ks over q): two tiles
             // at a time are one 16-byte + one 8-byte read per input row and one 16-byte read per gradient row
-            const float* gp = ga - 4 * q + (2 * wr) * TW + 8 * q;          // ga = plane p + 4 q: back to the plane, then column 8 q
-            const float* xp = xa - 4 * q + (2 * wr) * XP + 8 * q;
+#pragma unroll
+            for (int tr = 0; tr < RPW / 2; ++tr) {                          // this wave's rows of tiles (RPW output rows)
+            const float* gp = ga - 4 * q + (wr * RPW + 2 * tr) * TW + 8 * q;          // ga = plane p + 4 q: back to the plane, then column 8 q
+            const float* xp = xa - 4 * q + (wr * RPW + 2 * tr) * XP + 8 * q;
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
                 float xr[4][6], gr[2][4];
@@ -2143,6 +2145,7 @@ __global__ __launch_bounds__(NW * 64, (WINO && RES != 0) ? 2 : (COT * CIT == 1) 
                             acc[u * 4 + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[u][v], V[u][v], acc[u * 4 + v], 0, 0, 0);
                 }
             }
+            }
         } else
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
@@ -2179,10 +2182,10 @@ __global__ __launch_bounds__(NW * 64, (WINO && RES != 0) ? 2 : (COT * CIT == 1) 
         __syncthreads();
     }
     if (WINO) {
-        // thread (l, u): row u of the summed 4x4 position tile of lane l (waves in fixed order), multiplied by G from the right:
-        // Z[u][j] = sum_v s_v dU[u][v] G[v][j],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  s = (1, 1, 1, -1) (see the MFMA section)
-        const int l = tid & 63, u = tid >> 6;
-        float4 du[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
+        // item (l, u, o): row u of the summed 4x4 position tile of lane l of sub-slice o (its WR waves in fixed order), multiplied by G
+        // from the right:  Z[u][j] = sum_v s_v dU[u][v] G[v][j],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  s = (1, 1, 1, -1) (MFMA section)
+        constexpr int ITEMS = WO * 4 * 64, NIT = (ITEMS + NT - 1) / NT;
+        float4 du[NIT][4];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half) __syncthreads();
@@ -2192,31 +2195,44 @@ __global__ __launch_bounds__(NW * 64, (WINO && RES != 0) ? 2 : (COT * CIT == 1) 
                 red[(wave * 8 + t) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
             __syncthreads();
-            if ((u >> 1) == half) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float4 sum = red[(0 * 8 + (u & 1) * 4 + v) * 64 + l];
+            for (int it = 0; it < NIT; ++it) {
+                const int item = tid + it * NT, l = item & 63, u = (item >> 6) & 3, o = item >> 8;
+                if (item < ITEMS && (u >> 1) == half) {
 #pragma unroll
-                    for (int w = 1; w < 4; ++w) sum = f4add(sum, red[(w * 8 + (u & 1) * 4 + v) * 64 + l]);
-                    du[v] = sum;
+                    for (int v = 0; v < 4; ++v) {
+                        float4 sum = red[((0 * WO + o) * 8 + (u & 1) * 4 + v) * 64 + l];        // wave index = wr * WO + wo
+#pragma unroll
+                        for (int w = 1; w < WR; ++w) sum = f4add(sum, red[((w * WO + o) * 8 + (u & 1) * 4 + v) * 64 + l]);
+                        du[it][v] = sum;
+                    }
                 }
             }
         }
-        const float su = u == 3 ? -1.f : 1.f;
-        const float4 h12p = f4scale(f4add(du[1], du[2]), 0.5f), h12m = f4scale(f4add(du[1], f4scale(du[2], -1.f)), 0.5f);
-        const float4 z0 = f4scale(f4add(du[0], h12p), su), z1 = f4scale(h12m, su), z2 = f4scale(f4add(h12p, f4scale(du[3], -1.f)), su);
         __syncthreads();                                     // every thread has read its part of `red`
-        red[(u * 3 + 0) * 64 + l] = z0; red[(u * 3 + 1) * 64 + l] = z1; red[(u * 3 + 2) * 64 + l] = z2;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * NT, l = item & 63, u = (item >> 6) & 3, o = item >> 8;
+            if (item < ITEMS) {
+                const float su = u == 3 ? -1.f : 1.f;
+                const float4 h12p = f4scale(f4add(du[it][1], du[it][2]), 0.5f), h12m = f4scale(f4add(du[it][1], f4scale(du[it][2], -1.f)), 0.5f);
+                red[((o * 4 + u) * 3 + 0) * 64 + l] = f4scale(f4add(du[it][0], h12p), su);
+                red[((o * 4 + u) * 3 + 1) * 64 + l] = f4scale(h12m, su);
+                red[((o * 4 + u) * 3 + 2) * 64 + l] = f4scale(f4add(h12p, f4scale(du[it][3], -1.f)), su);
+            }
+        }
         __syncthreads();
-        // thread (l, i < 3): dW[i][j] = sum_u G^T[i][u] Z[u][j]
-        if (u < 3) {
+        // item (l, i < 3, o): dW[i][j] = sum_u G^T[i][u] Z[u][j]
+        for (int item = tid; item < WO * 3 * 64; item += NT) {
+            const int l = item & 63, i = (item >> 6) % 3, o = (item >> 6) / 3;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float4 z_0 = red[(0 * 3 + j) * 64 + l], z_1 = red[(1 * 3 + j) * 64 + l], z_2 = red[(2 * 3 + j) * 64 + l], z_3 = red[(3 * 3 + j) * 64 + l];
+                const float4 z_0 = red[((o * 4 + 0) * 3 + j) * 64 + l], z_1 = red[((o * 4 + 1) * 3 + j) * 64 + l];
+                const float4 z_2 = red[((o * 4 + 2) * 3 + j) * 64 + l], z_3 = red[((o * 4 + 3) * 3 + j) * 64 + l];
                 const float4 p12 = f4scale(f4add(z_1, z_2), 0.5f), m12 = f4scale(f4add(z_1, f4scale(z_2, -1.f)), 0.5f);
-                const float4 v = u == 0 ? f4add(z_0, p12) : u == 1 ? m12 : f4add(p12, z_3);
-                const int ci_l = l & 15, co_l = 4 * (l >> 4);
-                float* op = slab + ((long)(u * 3 + j) * CO_S + co_l) * CI_S + ci_l;
+                const float4 v = i == 0 ? f4add(z_0, p12) : i == 1 ? m12 : f4add(p12, z_3);
+                const int ci_l = (o % CIT) * 16 + (l & 15), co_l = (o / CIT) * 16 + 4 * (l >> 4);
+                float* op = slab + ((long)(i * 3 + j) * CO_S + co_l) * CI_S + ci_l;
                 op[0] = v.x; op[CI_S] = v.y; op[2 * CI_S] = v.z; op[3 * CI_S] = v.w;
             }
         }
@@ -2520,14 +2536,12 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision,
     if (!v1) {
         constexpr int NW = wgrad_f32_waves(COT, CIT);
         static const bool wino = !(getenv("NGAN_WINOGRAD_WGRAD") && getenv("NGAN_WINOGRAD_WGRAD")[0] == '0');    // A/B switch
-        if constexpr (COT == 1 && CIT == 1) {
-            if (wino && p.tw == 32) {
-                if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_f32_kernel<1, 1, 0, 32, 4, 1, 1>), grid, dim3(256), 0, s, a);
-                else if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<1, 1, 0, 32, 4, 0, 1>), grid, dim3(256), 0, s, a);
-                else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<1, 1, 1, 32, 4, 0, 1>), grid, dim3(256), 0, s, a);
-                else hipLaunchKernelGGL((wgrad_f32_kernel<1, 1, 2, 32, 4, 0, 1>), grid, dim3(256), 0, s, a);
-                return ngan::launch_status("ngan_conv3x3_wgrad(f32, winograd)");
-            }
+        if (wino && p.tw == 32) {
+            if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 1, 1>), grid, dim3(NW * 64), 0, s, a);
+            else if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 0, 1>), grid, dim3(NW * 64), 0, s, a);
+            else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 1, 32, NW, 0, 1>), grid, dim3(NW * 64), 0, s, a);
+            else hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 2, 32, NW, 0, 1>), grid, dim3(NW * 64), 0, s, a);
+            return ngan::launch_status("ngan_conv3x3_wgrad(f32, winograd)");
         }
         if (p.tw == 32) {
             if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 1>), grid, dim3(NW * 64), 0, s, a);
@@ -2828,7 +2842,7 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
     if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
     else {
-        const bool wino = !(getenv("NGAN_WINOGRAD_WGRAD") && getenv("NGAN_WINOGRAD_WGRAD")[0] == '0') && p.co_s == 16 && p.ci_s == 16 && p.tw == 32;
+        const bool wino = !(getenv("NGAN_WINOGRAD_WGRAD") && getenv("NGAN_WINOGRAD_WGRAD")[0] == '0') && p.tw == 32;
         snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw,
                  wgrad_f32_waves(p.co_s / 16, p.ci_s / 16), (resample == 0 && p.tw == 32 && W % 32 == 0) ? 1 : 0, wino ? 1 : 0);
     }
