@@ -115,7 +115,10 @@ int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int r
 /* weight gradient (ATen convolution_backward, weight part):
  *   gw[co][ci][ky][kx] = scale * sum_{b,y,x} g[b,y,x,co] * resample(x)[b,y+ky-1,x+kx-1,ci]      gw is OIHW
  * precision 1 requests the split-bf16 kernel (used when the image is at least 32 pixels wide, else exact fp32).
- * accumulate != 0: gw += ... (adds into an existing gradient buffer).  workspace: ngan_conv3x3_wgrad_workspace_bytes(...) bytes. */
+ * accumulate != 0: gw += ... (adds into an existing gradient buffer).  workspace: ngan_conv3x3_wgrad_workspace_bytes(...) bytes.
+ * precision 0 on images wider than 16 pixels contracts in Winograd form, dW = G^T [ sum over 2x2 output tiles (A dY A^T) . (B^T d B) ] G
+ * (fp32 arithmetic, 16 position accumulators instead of 9 taps, the back-transform applied to every partial sum before it is written:
+ * same slabs, same fixed-order reduction); NGAN_WINOGRAD_WGRAD=0 in the environment selects the direct contraction. */
 size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
                        int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate, int precision,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/ab_env.sh "VAR=a VAR2=b" "VAR=c" ...   -- one bench run per environment string, prints img/s and ms/step
-# (A/B switches: NGAN_FIRST_BLOCK=0, NGAN_UP2_FOLDED=0, NGAN_FIRST_ORDER_FUSION=0, NGAN_TILE_KERNEL=0, NGAN_MID_F32=0, NGAN_WGRAD_V1=1,
+# (A/B switches: NGAN_FIRST_BLOCK=0, NGAN_UP2_FOLDED=0, NGAN_FIRST_ORDER_FUSION=0, NGAN_TILE_KERNEL=0, NGAN_MID_F32=0, NGAN_WINOGRAD=0, NGAN_WINOGRAD_WGRAD=0, NGAN_WGRAD_V1=1,
 #  NGAN_WGRAD_SLABS=<n>, NGAN_PERSIST_WG_PER_CU=<n>, NGAN_LIB_PATH=<other build>)
 for envs in "$@"; do
   out=$(env $envs timeout -k 10 200 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1)
