@@ -63,7 +63,7 @@ int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int 
  *     64 pixels.  fp32 arithmetic throughout; its error against an fp64 convolution is no larger than the direct form's
  *     (tools/wino_check.py: relative L2 1.5e-7 against 2.6e-7).  NGAN_WINOGRAD=0 in the environment answers 0 instead.
  * (The function keeps its round-1 name; what it returns is the precision code for any requested precision.) */
-int ngan_conv3x3_uses_bf16x3(int B, int H, int W, int K, int N, int resample, int precision);
+int ngan_conv3x3_algorithm(int B, int H, int W, int K, int N, int resample, int precision);
 long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision);   /* size of `packed` in floats */
 
 /* Re-pack many weights with ONE launch (after an optimiser step).  `table` is a device array of n_entries records

@@ -72,7 +72,7 @@ NON_STATUS = {
     "ngan_first_block_table_floats": ([_I], _Z),
     "ngan_conv3x3_wgrad_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
     "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
-    "ngan_conv3x3_uses_bf16x3": ([_I, _I, _I, _I, _I, _I, _I], _I),
+    "ngan_conv3x3_algorithm": ([_I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_epilogue_fused": ([_I, _I, _I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_packed_floats": ([_I, _I, _I], _L),
     "ngan_conv3x3_pack_elements": ([_I, _I, _I, _I], _L),
@@ -171,8 +171,8 @@ def conv3x3_wgrad_kernel_name(B, H, W, Cin, Cout, resample, precision=0) -> str:
     return buf.value.decode()
 
 
-def conv3x3_uses_bf16x3(B, H, W, K, N, resample, precision) -> int:
-    return int(lib().ngan_conv3x3_uses_bf16x3(B, H, W, K, N, resample, precision))
+def conv3x3_algorithm(B, H, W, K, N, resample, precision) -> int:
+    return int(lib().ngan_conv3x3_algorithm(B, H, W, K, N, resample, precision))
 
 
 def conv3x3_epilogue_fused(B, H, W, K, N, resample, epilogue, out_mode, precision) -> bool:

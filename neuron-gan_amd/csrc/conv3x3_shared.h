@@ -6,6 +6,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+namespace ngan {
+// (a named namespace: the launchers that take it cross translation units)
+struct ConvArgs {
+    const float* x; const float* wp; const float* bias; float* y; float* rn;
+    int B, H, W, K, N, tiles_x, tiles_y;
+    float slope, eps;
+    const float* ay; const float* arn; float* aout;
+};
+}  // namespace ngan
+using ngan::ConvArgs;
+
 namespace {
 
 // Epilogues of the forward / input-gradient kernels (template parameter EPI):
@@ -18,12 +29,6 @@ namespace {
 //      y and rn are stored only if y != nullptr
 enum { EPI_NONE = 0, EPI_LRELU_PN = 1, EPI_PN_BWD = 2, EPI_TO_IMAGE = 3 };
 
-struct ConvArgs {
-    const float* x; const float* wp; const float* bias; float* y; float* rn;
-    int B, H, W, K, N, tiles_x, tiles_y;
-    float slope, eps;
-    const float* ay; const float* arn; float* aout;
-};
 
 __device__ __forceinline__ float4 pn_bwd4(float4 g, float4 yy, float s, float inv_r, float slope) {
     return make_float4((g.x - yy.x * s) * inv_r * (yy.x > 0.f ? 1.f : slope), (g.y - yy.y * s) * inv_r * (yy.y > 0.f ? 1.f : slope),

@@ -1,0 +1,414 @@
+// Winograd F(2x2, 3x3) forward / input-gradient kernel for the 32-channel layers (exact fp32 arithmetic, precision code 4):
+// K -> N in {16 -> 32, 32 -> 16, 32 -> 32} on large images with plain input (width a multiple of the 32-pixel tile).
+// Replaces conv2d + LeakyReLU + PixelNorm of /root/reference/models.py:252-268 for those layers.
+//
+// Why a kernel of its own (the 16 -> 16 form lives in conv3x3_tile.hip): v_mfma_f32_16x16x4_f32 runs on the vector-FMA lanes, so
+// past the direct form's ~100 TF loop skeleton the only lever is to issue fewer MFMAs, and Y = A^T [ (G g G^T) . (B^T d B) ] A
+// needs 16 instead of 36 products per 2x2 output tile and channel pair.  The transformed weights are 16 * K * N floats: 32 KB for
+// the mixed shapes, 64 KB for 32 -> 32 -- next to a 25 / 51 KB halo tile that is more than half a CU's LDS, so two workgroups per
+// CU cannot each hold a copy.  Instead ONE workgroup of 8 waves owns the CU (two waves per SIMD, the same occupancy as the 16 -> 16
+// kernel's two 4-wave workgroups) and the waves divide the work so that nothing but per-pixel scalars crosses between them:
+//
+//   shape     tile      waves  a wave owns                                     LDS (weights + tile)
+//   32 -> 32  8 x 32    8      one row of 16 Winograd tiles x ONE 16-channel   64 + 51 KB
+//                              half of the outputs (both input groups)
+//   32 -> 16  16 x 32   8      one row of 16 Winograd tiles, all 16 outputs    32 + 92 KB
+//   16 -> 32  8 x 32    4      one row of 16 Winograd tiles, both output       32 + 26 KB (two workgroups per CU)
+//                              halves
+//
+// Lane (p, q) of a wave owns Winograd tile p of its row: as the MFMA's B operand it supplies input channels 16 g + 4 q .. + 3 of
+// that tile (component s feeds MFMA s), as the D operand it receives output channels 16 mt + 4 q .. + 3 -- B^T d B on the 4x4 input
+// patch it reads itself and A^T M A on its own accumulators are lane-local, exactly as in the 16 -> 16 form.  In the 32 -> 32 layout the
+// two waves of a tile row repeat the input transform (64 packed additions per 16-channel group against 128 MFMAs) and exchange
+// only the per-pixel channel sums PixelNorm / its backward / ToImage need (one float per pixel and wave through LDS).
+// Staging, descriptors, padding by whole load instructions and the epilogue arithmetic are those of conv3x3_tile_kernel.
+#include "conv3x3_internal.h"
+
+namespace {
+
+template <int KG, int MT, int ROWS, int NWAVES, int EPI, int OUTMODE>
+__global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a, int n_tiles) {
+    constexpr int NT = NWAVES * 64, TR = ROWS / 2, NS = NWAVES / TR, MTW = MT / NS;   // tile rows; waves per tile row; n-tiles per wave
+    static_assert(NWAVES % TR == 0 && (NS == 1 || NS == 2) && MT % NS == 0, "wave split");
+    constexpr int HH_ = ROWS + 2, LP = 40, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int W_ELEMS = 16 * KG * MT * 256;
+    constexpr int K = KG * 16, N = MT * 16, PGW = 4;
+    constexpr int NL = KG * HH_ * 128 / NT, NST = NL + 1;        // interior loads per thread (+ one load for the two halo columns)
+    constexpr int N_HALO = KG * 2 * HH_ * 4;
+    static_assert((KG * HH_ * 128) % NT == 0 && N_HALO <= NT, "staging layout");
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    constexpr bool PNB = EPI == EPI_PN_BWD;
+    constexpr int NSUB = (PNB && OUTMODE) ? 4 : 1;                // per-pixel sums a wave contributes per pixel group
+    constexpr int XCH_ELEMS = NS > 1 ? 2 * NWAVES * PGW * NSUB * 16 : 4;
+    __shared__ __attribute__((aligned(16))) float smem[W_ELEMS + TILE_ELEMS + XCH_ELEMS];
+    float* wl = smem;
+    float* tile = smem + W_ELEMS;
+    float* xch = tile + TILE_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = wave % TR, nh = wave / TR;                     // this wave's row of Winograd tiles / its share of the output channels
+    const int p = lane & 15, q = lane >> 4;
+    const int cb = nh * MTW * 16;                                 // first output channel of this wave
+
+    for (int e = tid; e < W_ELEMS / 4; e += NT) st4(wl + e * 4, ld4(a.wp + e * 4));
+
+    const TileRun run = tile_run(n_tiles);
+    int t = run.t;
+    const int t_end = run.t_end;
+
+    // LDS image: one plane per 16-channel group; in a row, even and odd columns sit in separate halves (a lane reads columns
+    // 2p + b: position p + const), quads rotated by the column position as in the direct form -- conflict-free ds_read_b128
+    auto lds_slot = [&](int g, int c4, int ty, int tx) {
+        const int pos = (tx >> 1) + (tx & 1) * (LP / 2);
+        return g * PLANE + (ty * LP + pos) * 16 + ((c4 ^ (((pos >> 2) & 1) << 1)) << 2);
+    };
+    // ---- tile-invariant staging constants: byte offset from the halo origin (y0 - 1, x0 - 1), LDS float index ----
+    unsigned s_voff[NST];
+    int s_lds[NST];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int e = tid + i * NT;
+        const int g = e / (HH_ * 128), r = e % (HH_ * 128);
+        const int c4 = r & 3, pix = r >> 2, ty = pix >> 5, tx = (pix & 31) + 1;
+        s_voff[i] = (unsigned)(((ty * a.W + tx) * K + g * 16 + c4 * 4) * 4);
+        s_lds[i] = lds_slot(g, c4, ty, tx);
+    }
+    int h_bits;                                   // halo load: 1 = left column, 2 = right column, 4 = top row, 8 = unused lane
+    {
+        const int c4 = tid & 3, r = (tid >> 2) % HH_, sg = (tid >> 2) / HH_, side = sg & 1, g = sg >> 1;
+        const bool used = tid < N_HALO;
+        const int tx = side ? 33 : 0;
+        s_voff[NL] = used ? (unsigned)(((r * a.W + tx) * K + g * 16 + c4 * 4) * 4) : OOB;
+        s_lds[NL] = lds_slot(used ? g : 0, c4, used ? r : 0, tx);
+        h_bits = used ? ((side ? 2 : 1) | (r == 0 ? 4 : 0)) : 8;
+    }
+    int wrd[4];                                    // LDS float index of column 2p + b of a tile row, channel quad q
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int pos = p + (b >> 1) + (b & 1) * (LP / 2);
+        wrd[b] = pos * 16 + ((q ^ (((pos >> 2) & 1) << 1)) << 2);
+    }
+    // ---- tile-invariant epilogue constants: this lane's output byte offsets from the tile origin; pixel group pg = pixel
+    // (pg >> 1, pg & 1) of the lane's 2x2 output tile ----
+    constexpr int OS = OUTMODE ? 2 : 1;            // the pool-adjoint store writes a 2x2 block of a (2H, 2W) tensor per computed pixel
+    const int Wo = OS * a.W;
+    unsigned e_voff[PGW], p_voff[PGW];             // byte offset of this lane's first channel / of the pixel in a 1-channel tensor
+#pragma unroll
+    for (int pg = 0; pg < PGW; ++pg) {
+        const int row = 2 * tr + (pg >> 1), col = 2 * p + (pg & 1);
+        e_voff[pg] = (unsigned)((((OS * row) * Wo + OS * col) * N + cb + q * 4) * 4);
+        p_voff[pg] = (unsigned)(((OS * row) * Wo + OS * col) * 4);
+    }
+    unsigned t_voff = 0;                           // ToImage: lane group q finishes pixel group q
+    if (EPI == EPI_TO_IMAGE) t_voff = (unsigned)(((2 * tr + (q >> 1)) * a.W + 2 * p + (q & 1)) * 4);
+
+    auto decode = [&](int tt, int& b, int& y0, int& x0) {
+        const int txi = tt % a.tiles_x; tt /= a.tiles_x;
+        const int tyi = tt % a.tiles_y;
+        b = tt / a.tiles_y;
+        y0 = tyi * ROWS; x0 = txi * 32;
+    };
+    const unsigned img_bytes = (unsigned)(a.H * a.W * K) * 4u;
+    float4 stg[NST];
+    auto issue = [&](int tt) {
+        int b, y0, x0;
+        decode(tt, b, y0, x0);
+        const int soff = ((y0 - 1) * a.W + (x0 - 1)) * K * 4;                 // negative on the top row / for the first tile
+        const char* base = reinterpret_cast<const char*>(a.x + (long)b * a.H * a.W * K) + soff;
+        const unsigned nrec = img_bytes - (unsigned)soff;                     // bytes from `base` to the end of the image
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, nrec, 0x00020000);
+        // a wave's load i covers 64 consecutive items = half a tile row of one channel group: where that is the TOP halo row of a
+        // tile on the image's first row it reads through a descriptor without records, i.e. zeros (a whole-instruction decision)
+        const __amdgpu_buffer_rsrc_t rsrc_zero = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const bool top = y0 == 0 && (((i * NT + wave * 64) >> 7) % HH_) == 0;
+            stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(top ? rsrc_zero : rsrc, s_voff[i], 0, 0));
+        }
+        const int bad = (x0 == 0 ? 1 : 0) | (x0 + 32 >= a.W ? 2 : 0) | (y0 == 0 ? 4 : 0) | 8;
+        const unsigned hoff = (h_bits & bad) ? OOB : s_voff[NL];
+        stg[NL] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, hoff, 0, 0));
+    };
+    if (t < t_end) issue(t);
+
+    f32x4 bvec[MTW];
+    float4 wimg[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const float4 b4 = a.bias ? ld4(a.bias + cb + mt * 16 + q * 4) : f4zero();
+        bvec[mt] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+        wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + cb + mt * 16 + q * 4) : f4zero();
+    }
+    const float inv_n = 1.0f / (float)N;
+    const f32x2 slope2 = {a.slope, a.slope};
+    // partial per-pixel sums of the NS waves that share a tile row: every wave leaves its own in LDS, a workgroup barrier, then adds
+    // its partner's (a + b in one wave, b + a in the other: the same float).  `slot` separates the exchanges of one epilogue.
+    const int partner = nh ? wave - TR : wave + TR;
+    auto exchange = [&](float* vals, int nvals, int slot) {
+        if (NS == 1) return;
+        float* mine = xch + ((slot * NWAVES + wave) * PGW * NSUB) * 16;
+        const float* theirs = xch + ((slot * NWAVES + partner) * PGW * NSUB) * 16;
+        if (q == 0)
+            for (int j = 0; j < nvals; ++j) mine[j * 16 + p] = vals[j];
+        __syncthreads();
+        for (int j = 0; j < nvals; ++j) vals[j] += theirs[j * 16 + p];
+    };
+
+    while (t < t_end) {
+        int b, y0, x0;
+        decode(t, b, y0, x0);
+        __syncthreads();   // previous tile's MFMAs have finished reading `tile` (and its exchange buffers have been read)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) st4(&tile[s_lds[i]], stg[i]);
+        if (tid < N_HALO) st4(&tile[s_lds[NL]], stg[NL]);
+        __syncthreads();
+        const int tn = t + run.step;
+        if (tn < t_end) issue(tn);   // in flight while this tile is computed
+
+        // ---- per-tile scalars of the epilogue (the tile's byte offset is ADDED to the per-lane constants, one v_add per access:
+        // a buffer store with an SGPR soffset reads its data registers late, conv3x3_tile_kernel) ----
+        const long img = (long)b * a.H * a.W;
+        const int pix0 = (OS * y0) * Wo + OS * x0;                       // first output pixel of the tile inside its image
+        const unsigned y_soff = (unsigned)pix0 * (N * 4), p_soff = (unsigned)pix0 * 4u;
+        const unsigned out_bytes = (unsigned)(OS * a.H * Wo * N) * 4u, px_bytes = (unsigned)(OS * a.H * Wo) * 4u;
+        __amdgpu_buffer_rsrc_t y_rsrc, rn_rsrc, ay_rsrc, arn_rsrc;
+        if (EPI != EPI_TO_IMAGE || a.y) y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img * (OS * OS) * N, 0, out_bytes, 0x00020000);
+        // (no stored activation -- the inference form of epilogue 3 -- means no stored norm either: a descriptor without records)
+        if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE)
+            rn_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rn + img, 0, (EPI == EPI_LRELU_PN || a.y) ? px_bytes : 0u, 0x00020000);
+        if (PNB) {
+            ay_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ay) + img * (OS * OS) * N, 0, out_bytes, 0x00020000);
+            arn_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.arn) + img * (OS * OS), 0, px_bytes, 0x00020000);
+        }
+
+        // ---- Winograd section: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], A^T = [1 1 1 0; 0 1 -1 -1]; transforms on register
+        // pairs (v_pk_add_f32 / v_pk_fma_f32), G g G^T done by the packing kernel (layout [position][n-tile][k-group][lane][4]) ----
+        const f32x2 m1 = opaque_minus_one();
+        f32p bd[KG][4][4];                           // B^T d: rows transformed, columns still in pixel space
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const float* trow = tile + g * PLANE + (2 * tr) * (LP * 16);
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const f32p d0 = pk2(*reinterpret_cast<const f32x4*>(trow + 0 * LP * 16 + wrd[bb])), d1 = pk2(*reinterpret_cast<const f32x4*>(trow + 1 * LP * 16 + wrd[bb]));
+                const f32p d2 = pk2(*reinterpret_cast<const f32x4*>(trow + 2 * LP * 16 + wrd[bb])), d3 = pk2(*reinterpret_cast<const f32x4*>(trow + 3 * LP * 16 + wrd[bb]));
+                bd[g][0][bb] = psub(d0, d2, m1); bd[g][1][bb] = d1 + d2; bd[g][2][bb] = psub(d2, d1, m1); bd[g][3][bb] = psub(d1, d3, m1);
+            }
+        }
+        f32p accp[PGW][MTW];                         // outputs: pixel group (row a, column b) of the 2x2 tile = a * 2 + b
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            f32x4 m[MTW][4];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[mt][u] = (u == 1 && v == 1) ? bvec[mt] : (f32x4){0.f, 0.f, 0.f, 0.f};   // A^T e11 A = all ones: the bias
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                f32p vv[4];                          // (B^T d B)[u][v]
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    vv[u] = v == 0 ? psub(bd[g][u][0], bd[g][u][2], m1) : v == 1 ? bd[g][u][1] + bd[g][u][2]
+                          : v == 2 ? psub(bd[g][u][2], bd[g][u][1], m1) : psub(bd[g][u][1], bd[g][u][3], m1);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    f32x4 uu[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        uu[u] = *reinterpret_cast<const f32x4*>(&wl[(((u * 4 + v) * MT + nh * MTW + mt) * KG + g) * 256 + lane * 4]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            m[mt][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(uu[u][i], i < 2 ? vv[u].l[i & 1] : vv[u].h[i & 1], m[mt][u], 0, 0, 0);
+                }
+            }
+            // A^T M (rows), then the column transform accumulated as v advances: column 0 = t0 + t1 + t2, column 1 = t1 - t2 - t3
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const f32p ta0 = pk2(m[mt][0]) + pk2(m[mt][1]) + pk2(m[mt][2]);
+                const f32p ta1 = psub(psub(pk2(m[mt][1]), pk2(m[mt][2]), m1), pk2(m[mt][3]), m1);
+                if (v == 0) { accp[0][mt] = ta0; accp[2][mt] = ta1; }
+                else if (v == 1) { accp[0][mt] = accp[0][mt] + ta0; accp[2][mt] = accp[2][mt] + ta1; accp[1][mt] = ta0; accp[3][mt] = ta1; }
+                else if (v == 2) { accp[0][mt] = accp[0][mt] + ta0; accp[2][mt] = accp[2][mt] + ta1; accp[1][mt] = psub(accp[1][mt], ta0, m1); accp[3][mt] = psub(accp[3][mt], ta1, m1); }
+                else { accp[1][mt] = psub(accp[1][mt], ta0, m1); accp[3][mt] = psub(accp[3][mt], ta1, m1); }
+            }
+        }
+
+        // ---- epilogue: lane holds channels cb + 16 mt + 4q .. + 3 of its four pixels ----
+        f32x2 lo[PGW][MTW], hi[PGW][MTW];
+#pragma unroll
+        for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) { lo[pg][mt] = accp[pg][mt].l; hi[pg][mt] = accp[pg][mt].h; }
+
+        // PixelNorm-backward operands (same shape as the output): every load of the tile before its first store, awaited with
+        // vmcnt(0) (loads and stores retire out of order with each other under one counter: conv3x3_tile_kernel)
+        float4 yy[PNB ? PGW * NSUB : 1][MTW];
+        float rr[PNB ? PGW * NSUB : 1];
+        if (PNB) {
+            const unsigned row1 = (unsigned)(Wo * N * 4), prow1 = (unsigned)(Wo * 4);
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) {
+                    const unsigned eo = e_voff[pg] + y_soff + ((sub >> 1) ? row1 : 0u) + (sub & 1) * (N * 4);
+                    const unsigned po = p_voff[pg] + p_soff + ((sub >> 1) ? prow1 : 0u) + (sub & 1) * 4;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+                        yy[PNB ? pg * NSUB + sub : 0][mt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ay_rsrc, eo + mt * 64, 0, 0));
+                    rr[PNB ? pg * NSUB + sub : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arn_rsrc, po, 0, 0));
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        float timg = 0.f;
+        if (EPI == EPI_LRELU_PN || EPI == EPI_TO_IMAGE) {
+            float ss[PGW];
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) {
+                f32x2 sq = {0.f, 0.f};
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const f32x2 sl = lo[pg][mt] * slope2, sh = hi[pg][mt] * slope2;      // LeakyReLU, 0 <= slope <= 1: one v_max each
+                    lo[pg][mt] = (f32x2){vmax1(lo[pg][mt].x, sl.x), vmax1(lo[pg][mt].y, sl.y)};
+                    hi[pg][mt] = (f32x2){vmax1(hi[pg][mt].x, sh.x), vmax1(hi[pg][mt].y, sh.y)};
+                    sq = mt == 0 ? lo[pg][mt] * lo[pg][mt] : __builtin_elementwise_fma(lo[pg][mt], lo[pg][mt], sq);
+                    sq = __builtin_elementwise_fma(hi[pg][mt], hi[pg][mt], sq);
+                }
+                ss[pg] = sum_rows4(sq.x + sq.y);
+            }
+            exchange(ss, PGW, 0);
+            float dd[PGW];
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg) {
+                const float m = ss[pg] * inv_n + a.eps;
+                const float inv = __builtin_amdgcn_rsqf(m);
+                const f32x2 inv2 = {inv, inv};
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) { lo[pg][mt] *= inv2; hi[pg][mt] *= inv2; }
+                // the norm: one lane per pixel stores (of one wave), the others' offset is out of range
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m * inv), rn_rsrc, (q == 0 && nh == 0) ? p_voff[pg] + p_soff : OOB, 0, 0);
+                if (EPI == EPI_TO_IMAGE) {
+                    f32x2 d2 = {0.f, 0.f};
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        d2 = __builtin_elementwise_fma(lo[pg][mt], (f32x2){wimg[mt].x, wimg[mt].y}, d2);
+                        d2 = __builtin_elementwise_fma(hi[pg][mt], (f32x2){wimg[mt].z, wimg[mt].w}, d2);
+                    }
+                    dd[pg] = sum_rows4(d2.x + d2.y);
+                }
+            }
+            if (EPI == EPI_TO_IMAGE) {
+                exchange(dd, PGW, 1);
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg)
+                    if (q == pg) timg = dd[pg];     // all four q-lanes hold pixel group pg's sum; lane group q keeps the one it will finish
+            }
+        }
+        if (PNB) {
+            // backward of the LeakyReLU -> PixelNorm that produced this layer's input, applied to the gradient just computed; with the
+            // pool-adjoint store (OUTMODE 1) the value * 0.25 goes to four pixels, each with its own operands
+            if (OUTMODE) {
+                const f32x2 quarter = {0.25f, 0.25f};
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) { lo[pg][mt] *= quarter; hi[pg][mt] *= quarter; }
+            }
+            float s[PGW * NSUB];
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        const float4 y4 = yy[PNB ? pg * NSUB + sub : 0][mt];
+                        acc += lo[pg][mt].x * y4.x + lo[pg][mt].y * y4.y + hi[pg][mt].x * y4.z + hi[pg][mt].y * y4.w;
+                    }
+                    s[pg * NSUB + sub] = sum_rows4(acc);
+                }
+            exchange(s, PGW * NSUB, 0);
+            const unsigned row1 = (unsigned)(Wo * N * 4);
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) {
+                    const float sm = s[pg * NSUB + sub] * inv_n;
+                    const float inv_r = 1.0f / rr[PNB ? pg * NSUB + sub : 0];
+                    const unsigned eo = e_voff[pg] + y_soff + ((sub >> 1) ? row1 : 0u) + (sub & 1) * (N * 4);
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        const float4 o = pn_bwd4(make_float4(lo[pg][mt].x, lo[pg][mt].y, hi[pg][mt].x, hi[pg][mt].y), yy[PNB ? pg * NSUB + sub : 0][mt], sm, inv_r, a.slope);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), y_rsrc, eo + mt * 64, 0, 0);
+                    }
+                }
+        } else if (OUTMODE == 0) {
+            if (EPI != EPI_TO_IMAGE || a.y) {
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        const u32x4 v = __builtin_bit_cast(u32x4, make_float4(lo[pg][mt].x, lo[pg][mt].y, hi[pg][mt].x, hi[pg][mt].y));
+                        __builtin_amdgcn_raw_buffer_store_b128(v, y_rsrc, e_voff[pg] + y_soff + mt * 64, 0, 0);
+                    }
+            }
+        } else {
+            // pool-adjoint store without an epilogue: the value * 0.25 to the 2x2 block (2gy + i, 2gx + j)
+            const unsigned row1 = (unsigned)(Wo * N * 4);
+            const f32x2 quarter = {0.25f, 0.25f};
+#pragma unroll
+            for (int pg = 0; pg < PGW; ++pg)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const f32x2 l = lo[pg][mt] * quarter, h = hi[pg][mt] * quarter;
+                    const u32x4 v = __builtin_bit_cast(u32x4, make_float4(l.x, l.y, h.x, h.y));
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, y_rsrc, e_voff[pg] + y_soff + ((sub >> 1) ? row1 : 0u) + (sub & 1) * (N * 4) + mt * 64, 0, 0);
+                }
+        }
+        if (EPI == EPI_TO_IMAGE) {
+            // one tanh per lane instead of four: lane group q finishes pixel group q (same tanhf as the standalone ToImage kernel)
+            const float tv = tanhf(timg);
+            const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.aout + img, 0, px_bytes, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), t_rsrc, nh == 0 ? t_voff + p_soff : OOB, 0, 0);
+        }
+        t = tn;
+    }
+}
+
+template <int KG, int MT, int ROWS, int NWAVES, int EPI, int OUTMODE>
+int launch_wino(ConvArgs a, hipStream_t s) {
+    a.tiles_x = a.W / 32;
+    a.tiles_y = ngan::ceil_div(a.H, ROWS);
+    const int n_tiles = a.B * a.tiles_x * a.tiles_y;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_wino_kernel<KG, MT, ROWS, NWAVES, EPI, OUTMODE>, NWAVES * 64, 0) != hipSuccess || n < 1) n = 1;
+        per_cu = n > 4 ? 4 : n;
+    }
+    const int grid = persistent_grid(n_tiles, 256 * per_cu);
+    hipLaunchKernelGGL((conv3x3_wino_kernel<KG, MT, ROWS, NWAVES, EPI, OUTMODE>), dim3(grid), dim3(NWAVES * 64), 0, s, a, n_tiles);
+    return ngan::launch_status("ngan_conv3x3_fwd(winograd)");
+}
+
+template <int KG, int MT, int ROWS, int NWAVES>
+int dispatch_wino(const ConvArgs& a, int epi, int outmode, hipStream_t s) {
+    if (epi == EPI_PN_BWD) return outmode == 1 ? launch_wino<KG, MT, ROWS, NWAVES, EPI_PN_BWD, 1>(a, s) : launch_wino<KG, MT, ROWS, NWAVES, EPI_PN_BWD, 0>(a, s);
+    if (epi == EPI_TO_IMAGE) return launch_wino<KG, MT, ROWS, NWAVES, EPI_TO_IMAGE, 0>(a, s);
+    if (outmode == 1) return launch_wino<KG, MT, ROWS, NWAVES, EPI_NONE, 1>(a, s);
+    return epi ? launch_wino<KG, MT, ROWS, NWAVES, EPI_LRELU_PN, 0>(a, s) : launch_wino<KG, MT, ROWS, NWAVES, EPI_NONE, 0>(a, s);
+}
+
+}  // namespace
+
+int ngan::conv3x3_wino_tile_rows(int mtw, int kg) { return (kg == 2 && mtw == 1) ? 16 : 8; }
+
+// plain input, a.W % 32 == 0, (mtw, kg) in {(2, 2), (1, 2), (2, 1)} (the caller checks)
+int ngan::conv3x3_wino_launch(const ConvArgs& a, int mtw, int kg, int epilogue, int out_mode, hipStream_t s) {
+    if (kg == 2 && mtw == 2) return dispatch_wino<2, 2, 8, 8>(a, epilogue, out_mode, s);
+    if (kg == 2) return dispatch_wino<2, 1, 16, 8>(a, epilogue, out_mode, s);
+    return dispatch_wino<1, 2, 8, 4>(a, epilogue, out_mode, s);
+}

@@ -140,6 +140,16 @@ def clear_packed():
     bump_weight_epoch()
 
 
+def registry_size():
+    """number of persistent packed-weight copies registered so far (the step driver compares it around a capture's warm-up)"""
+    return len(_registry)
+
+
+def table_tensors():
+    """the device re-pack tables currently cached (a captured graph that contains their launches must keep them alive)"""
+    return [c[0] for c in _table.values()] if isinstance(_table, dict) else []
+
+
 def refresh_packed(owner=None, params=None):
     """Re-pack the registered packed copies with ONE launch; returns the number of entries refreshed.  With `params` (an iterable
     of parameters) and `owner` (any hashable tag for that set, e.g. id of the optimiser) only the copies of those parameters are
@@ -234,7 +244,7 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope):
         raise RuntimeError(f"conv3x3: input has {x.shape[3]} channels, weight expects {cin}")
     y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32)
     rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if epilogue else None
-    prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
+    prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
     packed = _packed(weight, 0, scale, prec)
     _C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0, float(slope), PIXELNORM_EPS, prec,
             _C.CONV_SKIP_BORDER if prec == 3 else 0)
@@ -250,7 +260,7 @@ def _run_dgrad(g, weight, resample, scale, link=None):
     cin = weight.shape[1]
     if cout != weight.shape[0]:
         raise RuntimeError(f"conv3x3 dgrad: gradient has {cout} channels, weight has {weight.shape[0]} outputs")
-    prec = _C.conv3x3_uses_bf16x3(b, h, w, cout, cin, 0, _conv_precision)
+    prec = _C.conv3x3_algorithm(b, h, w, cout, cin, 0, _conv_precision)
     packed = _packed(weight, 1, scale, prec)
     epi = EPI_PN_BWD if link is not None else EPI_NONE
     ay, arn, slope = (link.y, link.rn, float(link.slope)) if link is not None else (None, None, 0.0)
@@ -443,7 +453,7 @@ class ConvLReLUPNToImage(Function):
         y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32) if keep else None
         rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if keep else None
         t = torch.empty((b, h, w, 1), device=x.device, dtype=torch.float32)
-        prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
+        prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
         _C.call("ngan_conv3x3_fwd_ex", x, _packed(weight, 0, scale, prec), bias, y, rn, w_img.detach().reshape(-1), None, t,
                 b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, float(slope), PIXELNORM_EPS, prec, 0)
         if keep:
@@ -476,7 +486,7 @@ def to_image_fusable(x, weight, w_img, resample):
         return False
     b, h, w = _conv_out_hw(x, resample)
     cout, cin = weight.shape[0], weight.shape[1]
-    prec = _C.conv3x3_uses_bf16x3(b, h, w, cin, cout, resample, _conv_precision)
+    prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
     return _C.conv3x3_epilogue_fused(b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, prec)
 
 

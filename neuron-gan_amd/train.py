@@ -230,7 +230,7 @@ class PGGANTrainer:
         if self.device.type == "cuda" and dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == "nccl":
             self._comm_stream = torch.cuda.Stream(device=self.device)
         self._graphs = {}          # input shape -> captured graphs of this stage (capture / replay)
-        self._graph = None
+        self._graph = self._entry = None
         self.refresh_stage()
         ops.bump_weight_epoch()
 
@@ -247,7 +247,7 @@ class PGGANTrainer:
         self.flat_g.set_active(active_parameters(self.G))
         self.flat_d.set_active(active_parameters(self.D))
         self._graphs = {}          # the captured graphs belong to the previous stage's module structure
-        self._graph = None
+        self._graph = self._entry = None
 
     def start_epoch(self, epoch, transit_sch=()):
         """Per-epoch alpha advance and growth (train.py:318-333).  Returns True if the structure changed."""
@@ -434,6 +434,7 @@ class PGGANTrainer:
         if segmented and self.n_critic != 1:
             raise RuntimeError("segmented (data-parallel) capture supports n_critic = 1")
         static_real = real_example.clone()
+        n_packed_before = ops.registry_size()
         state = self._training_state()
         saved = [t.clone() for t in state]
         rng = torch.cuda.get_rng_state(self.device)
@@ -455,11 +456,42 @@ class PGGANTrainer:
         self.opt_g.repack()       # steps find them complete
         ops.refresh_packed()      # (copies of tensors that belong to neither optimiser)
         torch.cuda.synchronize()
+        if ops.registry_size() != n_packed_before and self._graphs:
+            # This shape registered packed-weight copies the earlier shapes' graphs know nothing about (the pack format of a layer
+            # can depend on the batch: ngan_conv3x3_algorithm).  The re-pack launches captured in those graphs run from tables that
+            # do not list the new copies, so a replay of them would leave the new copies stale for this shape's next replay:
+            # forget the earlier graphs; they are re-captured on next sight with complete tables (the registry no longer grows then).
+            self._graphs.clear()
+            self._graph = self._entry = None
         # With an RCCL process group alive its watchdog thread polls collective events (hipEventQuery) at any time.  HIP's GLOBAL
         # capture mode refuses such a call from ANY thread while a capture is active (hipErrorStreamCaptureUnsupported -> the
         # watchdog terminates the process); thread_local polices the capturing thread only.  The second rule (an event whose stream
         # is part of the capture) is what _on_comm_stream takes care of.  Both reproduced case by case: tools/capture_event_probe.py.
         mode = os.environ.get("NGAN_CAPTURE_MODE") or ("thread_local" if self._comm_stream is not None else "global")
+        # No cyclic garbage collection while a capture is active: a collection that happens to start inside the captured region runs
+        # the finalizers of whatever cyclic garbage earlier code left behind (graphs of a previous stage or trainer, events, tensors
+        # of released graph pools) on the capturing thread, and HIP aborts the process for some of those calls during a global-mode
+        # capture (seen once: `Fatal Python error: Aborted` under "Garbage-collecting" in the third capture of a process).
+        # torch.cuda.graph() no longer collects on entry by itself.  Collect now, then keep the collector off until the capture ends.
+        import gc
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            graphs, stats = self._capture_segments(segmented, mode, static_real, d_args, z_g)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
+        # Two things the captured launches reference besides the static input: (a) the stem's factor tensors (`StemGradExchange.sink`
+        # ran during THIS capture; another shape's capture overwrites stem.captured, and the eager `finish()` between replayed
+        # segments must read this graph's factors, not the most recent capture's); (b) the device re-pack tables whose pointers
+        # are baked into the captured Adam segments (ops drops its own references when a later capture registers new copies).
+        entry = (graphs, static_real, stats, self.stem.captured if self.stem is not None else None, ops.table_tensors())
+        self._graph, self._entry = graphs, entry
+        self._graphs[tuple(real_example.shape)] = entry
+        return graphs
+
+    def _capture_segments(self, segmented, mode, static_real, d_args, z_g):
         if not segmented:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode=mode):
@@ -480,10 +512,7 @@ class PGGANTrainer:
             torch.cuda.synchronize()
             self.flat_d.grad.zero_()                     # the exchanges above summed never-computed gradients: leave nothing behind
             self.flat_g.grad.zero_()
-        self._graph = graphs
-        self._static_real, self._static_stats = static_real, stats
-        self._graphs[tuple(real_example.shape)] = (graphs, static_real, stats)
-        return graphs
+        return graphs, stats
 
     def has_graph(self, shape):
         return tuple(shape) in self._graphs
@@ -496,12 +525,15 @@ class PGGANTrainer:
             if entry is None:
                 raise RuntimeError(f"no graphs captured for input shape {tuple(real.shape)}: call capture() first (and again after "
                                    f"every growth event)")
-            graphs, static_real, stats = entry
+            static_real = entry[1]
             static_real.copy_(real, non_blocking=True)
         else:
             if self._graph is None:
                 raise RuntimeError("call capture() first (and again after every growth event)")
-            graphs, stats = self._graph, self._static_stats
+            entry = self._entry
+        graphs, _, stats, stem_factors, _ = entry
+        if self.stem is not None:
+            self.stem.captured = stem_factors     # the factors THESE graphs fill (see capture())
         if len(graphs) == 1:
             graphs[0].replay()
         else:

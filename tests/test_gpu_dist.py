@@ -156,6 +156,25 @@ def _capture_worker(port, fixture, q):
         import time
         time.sleep(0.5)                                                   # several watchdog polls
         assert all(torch.equal(p, pe) for p, pe in zip(tr.flat_d.params, eager.flat_d.params))
+        # graphs cached for TWO input shapes (a ragged last batch), replayed A, B, A: each replay's eager stem exchange must read the
+        # factor tensors ITS graphs fill, not those of the most recent capture (round-2 advisor finding: the stem is most of G)
+        half = batch // 2
+        cut = lambda s, n: {k: v[:n].clone() for k, v in s.items()}
+        seq = [cut(steps[0], batch), cut(steps[1], half), cut(steps[2], batch)]
+        statics = {batch: static}
+        for s in (seq[0], seq[1], seq[0]):          # (a capture that registers new packed-weight copies drops the older graphs)
+            if not tr.has_graph(s["real"].shape):
+                st = statics.setdefault(s["real"].shape[0], {k: s[k].clone() for k in ("z_d", "z_gp", "eps", "z_g")})
+                tr.capture(s["real"], draws=st)
+        assert tr.has_graph(seq[0]["real"].shape) and tr.has_graph(seq[1]["real"].shape)
+        for s in seq:
+            eager.train_iteration(s["real"], s["z_d"], s["z_gp"], s["eps"], s["z_g"])
+            for k, v in statics[s["real"].shape[0]].items():
+                v.copy_(s[k])
+            tr.replay(s["real"])
+        torch.cuda.synchronize()
+        for name, p, pe in zip(tr.flat_g.names + tr.flat_d.names, tr.flat_g.params + tr.flat_d.params, eager.flat_g.params + eager.flat_d.params):
+            assert torch.equal(p, pe), f"{name}: cached graphs of two shapes (A, B, A) left the eager trajectory by {float((p - pe).abs().max())}"
         q.put("ok")
     except Exception as e:  # noqa: BLE001
         q.put(repr(e))

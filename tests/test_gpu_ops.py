@@ -203,7 +203,7 @@ def test_folded_bilinear_border_modes(ngan):
     ops.set_conv_precision("bf16x3")
     try:
         B, H, W, K, N = 2, 128, 256, 16, 16
-        prec = C.conv3x3_uses_bf16x3(B, H, W, K, N, 2, 1)
+        prec = C.conv3x3_algorithm(B, H, W, K, N, 2, 1)
         assert prec == 3
         torch.manual_seed(2)
         x = torch.randn(B, H // 2, W // 2, K, device=DEV)
@@ -521,7 +521,7 @@ def test_persistent_conv_with_many_tiles_per_workgroup(ngan, case, conv_precisio
     w = torch.randn(N, K, 3, 3)
     bias = torch.randn(N) if out_mode == 0 else None
     scale = 1.3868 / np.sqrt(9 * K)
-    prec = C.conv3x3_uses_bf16x3(B, H, W, K, N, 0, ops.PRECISIONS[conv_precision])
+    prec = C.conv3x3_algorithm(B, H, W, K, N, 0, ops.PRECISIONS[conv_precision])
     xd, wd = x.to(DEV), w.to(DEV)
     oh, ow = (2 * H, 2 * W) if out_mode else (H, W)
     y = torch.full((B, oh, ow, N), float("nan"), device=DEV)

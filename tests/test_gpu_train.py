@@ -138,6 +138,45 @@ def test_one_update_per_batch_with_a_ragged_last_batch(ngan):
     assert not torch.equal(w0, tr.flat_d.flat)
 
 
+def test_cached_graphs_of_two_shapes_replay_the_eager_trajectory(ngan):
+    """Graphs are cached per input shape.  Batch 16 and batch 8 at 64x64 choose DIFFERENT kernels and packed-weight formats for the
+    16 -> 16 layers (ngan_conv3x3_algorithm: the persistent / Winograd forms need >= 256 tiles), so the second capture registers
+    packed copies the first shape's re-pack table does not list.  Replaying A, B, A, B from the cache must stay bit-equal to eager
+    `train_iteration` (round-2 advisor findings: stale packed weights, re-pack tables freed under a live graph)."""
+    torch.manual_seed(11)
+    def make():
+        torch.manual_seed(11)
+        G = ngan.models.Generator_PG([32, 16, 16, 16], image_size_init=8, latent_dim=32)
+        D = ngan.models.Discriminator_PG([16, 16, 16, 32], image_size_init=8)
+        G.set_resolution(64, 1.0)
+        D.set_resolution(64, 1.0)
+        return ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), learning_rate=1e-3)
+    C = ngan._C
+    assert C.conv3x3_algorithm(16, 64, 64, 16, 16, 0, 0) != C.conv3x3_algorithm(8, 64, 64, 16, 16, 0, 0)
+    gen = torch.Generator().manual_seed(3)
+    def draw(b):
+        z = [torch.randn(b, 32, generator=gen) for _ in range(3)]
+        z = [(v / v.norm(dim=1, keepdim=True)).to(DEV) for v in z]
+        return dict(real=(torch.rand(b, 1, 64, 64, generator=gen) * 2 - 1).to(DEV), z_d=z[0], z_gp=z[1],
+                    eps=torch.rand(b, 1, 1, 1, generator=gen).to(DEV), z_g=z[2])
+    seq = [draw(16), draw(8), draw(16), draw(8)]
+    eager, tr = make(), make()
+    statics = {}
+    for s in seq[:3]:
+        if not tr.has_graph(s["real"].shape):
+            st = statics.setdefault(s["real"].shape[0], {k: s[k].clone() for k in ("z_d", "z_gp", "eps", "z_g")})
+            tr.capture(s["real"], draws=st)
+    assert tr.has_graph(seq[0]["real"].shape) and tr.has_graph(seq[1]["real"].shape)
+    for s in seq:
+        eager.train_iteration(s["real"], s["z_d"], s["z_gp"], s["eps"], s["z_g"])
+        for k, v in statics[s["real"].shape[0]].items():
+            v.copy_(s[k])
+        tr.replay(s["real"])
+    torch.cuda.synchronize()
+    for name, p, pe in zip(tr.flat_g.names + tr.flat_d.names, tr.flat_g.params + tr.flat_d.params, eager.flat_g.params + eager.flat_d.params):
+        assert torch.equal(p, pe), f"{name}: {float((p - pe).abs().max())}"
+
+
 def test_penalty_switched_off_draws_no_second_latent_batch(ngan):
     """grad_pen_lambda = 0 is the reference CLI's argparse default: D_grad_pen_loss returns 0 (loss_functions.py:179) and draws
     nothing.  The step driver must run (round 1 stacked a CPU scalar with device tensors) and must not generate the unused fakes."""

@@ -36,7 +36,7 @@ dev = "cuda:0"
 hin, win = ((a.H // 2, a.W // 2) if a.res == 2 else (a.H, a.W))
 x = torch.randn(a.B, hin, win, a.K, device=dev)
 w = torch.randn(a.N, a.K, 3, 3, device=dev)
-prec = C.conv3x3_uses_bf16x3(a.B, a.H, a.W, a.K, a.N, a.res, a.prec)
+prec = C.conv3x3_algorithm(a.B, a.H, a.W, a.K, a.N, a.res, a.prec)
 packed = ops._packed(w, 0, 0.1, prec)
 y = torch.empty(a.B, a.H, a.W, a.N, device=dev)
 rn = torch.empty(a.B, a.H, a.W, device=dev)

@@ -30,7 +30,7 @@ x = torch.randn(a.B, hin, win, a.K, device=dev)
 w = torch.randn(a.N, a.K, 3, 3, device=dev)
 flops = 2.0 * 9 * a.K * a.N * a.B * a.H * a.W
 if a.op == "fwd":
-    prec = C.conv3x3_uses_bf16x3(a.B, a.H, a.W, a.K, a.N, a.res, a.prec)
+    prec = C.conv3x3_algorithm(a.B, a.H, a.W, a.K, a.N, a.res, a.prec)
     packed = ops._packed(w, 0, 0.1, prec)
     oh, ow = (2 * a.H, 2 * a.W) if a.out else (a.H, a.W)
     y = torch.empty(a.B, oh, ow, a.N, device=dev)

@@ -14,7 +14,7 @@ def run(path):
     outs = []
     for (B, H, W, K, N, epi, om, pr) in SHAPES:
         torch.manual_seed(B + H + K + N + epi)
-        prec = C.conv3x3_uses_bf16x3(B, H, W, K, N, 0, pr)
+        prec = C.conv3x3_algorithm(B, H, W, K, N, 0, pr)
         x = torch.randn(B, H, W, K, device="cuda"); w = torch.randn(N, K, 3, 3, device="cuda")
         oh, ow = (2 * H, 2 * W) if om else (H, W)
         ay = torch.randn(B, oh, ow, N, device="cuda") if epi == 2 else (torch.randn(N, device="cuda") if epi == 3 else None)

@@ -13,7 +13,7 @@ gy = torch.randn(B, H, W, Cout).cuda()
 yy = y_ref; s = (gy.double() * yy).mean(-1, keepdim=True); m = torch.where(yy > 0, 1.0, 0.2)
 gc_ref = m * (gy.double() - yy * s) / r_ref.unsqueeze(-1)
 for prec in (0, 1):
-    p = C.conv3x3_uses_bf16x3(B, H, W, Cin, Cout, 0, prec)
+    p = C.conv3x3_algorithm(B, H, W, Cin, Cout, 0, prec)
     packed = torch.empty(C.conv3x3_packed_floats(Cout, Cin, p), device="cuda")
     C.call("ngan_conv3x3_pack_weights", w, packed, Cout, Cin, 0, scale, p)
     y = torch.empty(B, H, W, Cout, device="cuda"); rn = torch.empty(B, H, W, device="cuda")

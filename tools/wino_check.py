@@ -23,7 +23,7 @@ def run(path):
     for (B, H, W, epi, om, mode, res) in SHAPES:
         torch.manual_seed(B + H + W + epi + om)
         K = N = 16
-        prec = C.conv3x3_uses_bf16x3(B, H, W, K, N, res, 0)
+        prec = C.conv3x3_algorithm(B, H, W, K, N, res, 0)
         x = torch.randn(B, H // 2, W // 2, K, device="cuda") if res == 2 else torch.randn(B, H, W, K, device="cuda")
         w = torch.randn(N, K, 3, 3, device="cuda")
         oh, ow = (2 * H, 2 * W) if om else (H, W)
