@@ -64,6 +64,11 @@ inline int persistent_grid(int n_tiles, int resident) {
 // inside the loop.  (Measured on the older persistent kernel the same treatment was neutral to slightly negative -- its tile loop
 // is bound by VALU issue and LDS, not by the store drain -- so it keeps the compiler's placement.)
 __device__ __forceinline__ void pin_registers(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void pin_registers(f32x4& v) { asm volatile("" : "+v"(v)); }
+// Loop-invariant operands fetched in a persistent kernel's prologue (bias, colour weights) are pinned ONCE before the tile loop:
+// the compiler's wait-count pass is not path sensitive, so a load that may still be pending on the loop's entry edge turns the
+// first in-loop use of its registers into an `s_waitcnt vmcnt(0)` on EVERY iteration -- in the middle of the MFMA section, where
+// it also drains the next tile's prefetch issued just before (found in the ISA of the 16 -> 16 Winograd instances, round 3).
 // ... and not before `dep` has been computed (an accumulator of the last MFMA: the scheduler may not hoist the wait above the MFMAs)
 __device__ __forceinline__ void pin_registers_after(float4& v, float& dep) {
     asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dep));

@@ -163,14 +163,15 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : (MTW * KG == 1) ? (PREC ? 3 : 
             }
         }
     };
-    if (t < t_end) issue(t);
-
     float4 bv[MTW], wimg[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         bv[mt] = a.bias ? ld4(a.bias + mt * 16 + q * 4) : f4zero();
         wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + mt * 16 + q * 4) : f4zero();
     }
+    if (t < t_end) issue(t);
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) { pin_registers(bv[mt]); pin_registers(wimg[mt]); }     // (awaited once, here: conv3x3_internal.h)
     const float inv_n = 1.0f / (float)N;
 
     while (t < t_end) {

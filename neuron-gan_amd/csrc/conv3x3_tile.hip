@@ -140,8 +140,6 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : (MTW * KG == 1) ? (PREC ? 3 : 
         const unsigned hoff = (h_bits & bad) ? OOB : s_voff[NL];
         stg[NL] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, hoff, 0, 0));
     };
-    if (t < t_end) issue(t);
-
     f32x4 bvec[MTW];
     float4 wimg[MTW];
 #pragma unroll
@@ -150,6 +148,9 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : (MTW * KG == 1) ? (PREC ? 3 : 
         bvec[mt] = (f32x4){b4.x, b4.y, b4.z, b4.w};
         wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + mt * 16 + q * 4) : f4zero();
     }
+    if (t < t_end) issue(t);
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) { pin_registers(bvec[mt]); pin_registers(wimg[mt]); }     // (awaited once, here: conv3x3_internal.h)
     const float inv_n = 1.0f / (float)N;
     const f32x2 slope2 = {a.slope, a.slope};
 
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : (MTW * KG == 1) ? (PREC ? 3 : 
             if (BF) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
             else st4(&tile[s_lds[i]], stg[i]);
         }
+        pin_registers(stg[NL]);     // every wave awaits the halo load here (the waves that store nothing would carry it, un-awaited, into the next issue)
         if (tid < N_HALO) {
             if (BF) st_split<KG, PLANE>(tile, s_lds[NL], stg[NL]);
             else st4(&tile[s_lds[NL]], stg[NL]);

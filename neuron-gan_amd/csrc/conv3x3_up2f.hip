@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256, KG == 1 ? 3 : 2) void conv3x3_up2f_kernel(Conv
     issue(t);
 #pragma unroll
     for (int i = 0; i < NST; ++i) pin_registers(stg[i]);   // (no load is pending on entry to the loop: see pin_registers)
-    const float4 bv = a.bias ? ld4(a.bias + q * 4) : f4zero();
+    float4 bv = a.bias ? ld4(a.bias + q * 4) : f4zero();
+    pin_registers(bv);                                     // (awaited once, here: conv3x3_internal.h)
     const float inv_n = 1.0f / (float)N;
 
     while (t < t_end) {

@@ -119,18 +119,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, nrec, 0x00020000);
         // a wave's load i covers 64 consecutive items = half a tile row of one channel group: where that is the TOP halo row of a
         // tile on the image's first row it reads through a descriptor without records, i.e. zeros (a whole-instruction decision)
-        const __amdgpu_buffer_rsrc_t rsrc_zero = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0u, 0x00020000);
+        // (the choice is made on the descriptor's scalar record count, not between two descriptors: a select of whole descriptors
+        // came out of the compiler as a per-lane waterfall loop around every load)
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const bool top = y0 == 0 && (((i * NT + wave * 64) >> 7) % HH_) == 0;
-            stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(top ? rsrc_zero : rsrc, s_voff[i], 0, 0));
+            const int hrow = (i * NT + wave * 64) >> 7;              // halo row index over all channel groups: top rows are 0 and HH_
+            const bool top = y0 == 0 && (hrow == 0 || (KG == 2 && hrow == HH_));      // (scalar compares: a `% HH_` went through the VALU)
+            const __amdgpu_buffer_rsrc_t rsrc_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, top ? 0u : nrec, 0x00020000);
+            stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_i, s_voff[i], 0, 0));
         }
         const int bad = (x0 == 0 ? 1 : 0) | (x0 + 32 >= a.W ? 2 : 0) | (y0 == 0 ? 4 : 0) | 8;
         const unsigned hoff = (h_bits & bad) ? OOB : s_voff[NL];
         stg[NL] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, hoff, 0, 0));
     };
-    if (t < t_end) issue(t);
-
     f32x4 bvec[MTW];
     float4 wimg[MTW];
 #pragma unroll
@@ -139,6 +140,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         bvec[mt] = (f32x4){b4.x, b4.y, b4.z, b4.w};
         wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + cb + mt * 16 + q * 4) : f4zero();
     }
+    if (t < t_end) issue(t);
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) { pin_registers(bvec[mt]); pin_registers(wimg[mt]); }     // (awaited once, here: conv3x3_internal.h)
     const float inv_n = 1.0f / (float)N;
     const f32x2 slope2 = {a.slope, a.slope};
     // partial per-pixel sums of the NS waves that share a tile row: every wave leaves its own in LDS, a workgroup barrier, then adds
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         __syncthreads();   // previous tile's MFMAs have finished reading `tile` (and its exchange buffers have been read)
 #pragma unroll
         for (int i = 0; i < NL; ++i) st4(&tile[s_lds[i]], stg[i]);
+        pin_registers(stg[NL]);     // every wave awaits the halo load here (the waves that store nothing would carry it, un-awaited, into the next issue)
         if (tid < N_HALO) st4(&tile[s_lds[NL]], stg[NL]);
         __syncthreads();
         const int tn = t + run.step;

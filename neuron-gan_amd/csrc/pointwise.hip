@@ -423,6 +423,22 @@ __global__ void pool2_fwd_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
+// the same for C a multiple of 4: a thread takes 4 channels of an output pixel (4 x 16-byte loads, one 16-byte store); 32-bit
+// index arithmetic (the host checks the element count).  Same association as the scalar kernel: bit-identical.
+__global__ __launch_bounds__(256) void pool2_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y, int total4, int h, int w, int C4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c4 = i % C4;
+    int r = i / C4;
+    const int X = r % w; r /= w;                    // r = b * h + Y from here on
+    const int C = 4 * C4;
+    const long row = (long)2 * w * C;
+    const float* p = x + ((long)2 * r * 2 * w + 2 * X) * C + 4 * c4;
+    const float4 a = ld4(p), b = ld4(p + C), c = ld4(p + row), d = ld4(p + row + C);
+    st4(y + (long)i * 4, make_float4(0.25f * ((a.x + b.x) + (c.x + d.x)), 0.25f * ((a.y + b.y) + (c.y + d.y)),
+                                     0.25f * ((a.z + b.z) + (c.z + d.z)), 0.25f * ((a.w + b.w) + (c.w + d.w))));
+}
+
 __global__ void pool2_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int h, int w, int C) {
     const long total = (long)B * 4 * h * w * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -775,7 +791,16 @@ extern "C" int ngan_up2_adjoint(const float* a, float* o, int B, int h, int w, i
     }
     return ngan::launch_status("ngan_up2_adjoint");
 }
-RESAMPLE_API(ngan_pool2_fwd, pool2_fwd_kernel, (long)B * h * w * C)
+extern "C" int ngan_pool2_fwd(const float* a, float* o, int B, int h, int w, int C, void* stream) {
+    NGAN_REQUIRE(a && o, NGAN_ERR_ARG, "ngan_pool2_fwd: null pointer");
+    NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, "ngan_pool2_fwd: bad dims %d %d %d %d", B, h, w, C);
+    const long total = (long)B * h * w * C;
+    if (C % 4 == 0 && total / 4 < (1L << 31) - 256)
+        hipLaunchKernelGGL(pool2_fwd_v4_kernel, dim3(ceil_div(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, o, (int)(total / 4), h, w, C / 4);
+    else
+        hipLaunchKernelGGL(pool2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
+    return ngan::launch_status("ngan_pool2_fwd");
+}
 RESAMPLE_API(ngan_pool2_adjoint, pool2_adjoint_kernel, (long)B * 4 * h * w * C)
 
 extern "C" int ngan_lerp(const float* a, const float* b, const float* alpha, float* out, long n, void* stream) {

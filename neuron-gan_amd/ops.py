@@ -236,8 +236,30 @@ def _conv_out_hw(x, resample):
     return b, h, w
 
 
-def _run_conv(x, weight, bias, resample, scale, epilogue, slope):
-    """y (and rnorm) = epilogue(conv3x3(resample(x), scale*W) + bias)"""
+def _pool_first(resample):
+    """Exact-fp32 mode: a 2x2-average-pooled conv input is pooled by one streaming pass and the convolution then runs on the
+    quarter-size tensor with plain input (the Winograd / tile / mid kernels at 0.6 - 0.9 of the fp32 MFMA peak) instead of pooling
+    inside the generic kernel's staging (four dependent loads per staged element: 0.3 - 0.35).  The pooled copy also serves the
+    weight gradient of the same layer.  (nn.AvgPool2d in front of a block's first conv, reference models.py:252-254.)"""
+    return resample == RES_POOL2 and _conv_precision == 0 and _pool_first_allowed
+
+
+_pool_first_allowed = os.environ.get("NGAN_POOL_FIRST", "1") != "0"     # A/B switch for measurements and tests
+
+
+def _pooled(x):
+    b, h2, w2, c = x.shape
+    return _resample("ngan_pool2_fwd", x, (b, h2 // 2, w2 // 2, c), b, h2 // 2, w2 // 2, c)
+
+
+def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=None):
+    """y (and rnorm) = epilogue(conv3x3(resample(x), scale*W) + bias); keep_pooled: a list that receives the pooled input copy
+    when one was made (`_pool_first`)"""
+    if _pool_first(resample):
+        x = _pooled(x)
+        resample = RES_NONE
+        if keep_pooled is not None:
+            keep_pooled.append(x)
     b, h, w = _conv_out_hw(x, resample)
     cout, cin = weight.shape[0], weight.shape[1]
     if x.shape[3] != cin:
@@ -333,8 +355,12 @@ def flush_wgrad():
     return n
 
 
-def _run_wgrad(x, g, resample, scale, accumulate_into=None, role=0):
-    """role: 0 = weight gradient of a forward conv node, 1 = of an input-gradient node (ConvDgrad.backward); see flush_wgrad"""
+def _run_wgrad(x, g, resample, scale, accumulate_into=None, role=0, pooled=None):
+    """role: 0 = weight gradient of a forward conv node, 1 = of an input-gradient node (ConvDgrad.backward); see flush_wgrad.
+    pooled: the 2x2-averaged copy of x the forward pass made, if it kept one (`_pool_first`)"""
+    if _pool_first(resample):
+        x = pooled if pooled is not None else _pooled(x)
+        resample = RES_NONE
     b, h, w, cout = g.shape
     cin = x.shape[3]
     gw = accumulate_into if accumulate_into is not None else torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
@@ -370,7 +396,7 @@ def _channel_sum(g):
 # ---------------------------------------------------------------------------------------------------------
 # 3x3 convolution family
 # ---------------------------------------------------------------------------------------------------------
-def _conv_backward_tail(ctx, x, weight, gc, resample, scale, in_link, has_bias, bias_index=2):
+def _conv_backward_tail(ctx, x, weight, gc, resample, scale, in_link, has_bias, bias_index=2, pooled=None):
     """input / weight / bias gradients of a conv given the gradient gc w.r.t. its pre-activation (shared by the fused forms)"""
     gx = None
     if ctx.needs_input_grad[0]:
@@ -384,7 +410,7 @@ def _conv_backward_tail(ctx, x, weight, gc, resample, scale, in_link, has_bias, 
     gw = None
     if ctx.needs_input_grad[1] and _param_grads_wanted():
         if _accumulates_in_place(weight):
-            _run_wgrad(x, _c(gc), resample, scale, accumulate_into=weight.grad)   # weight.grad += ..., returns None to autograd
+            _run_wgrad(x, _c(gc), resample, scale, accumulate_into=weight.grad, pooled=pooled)   # weight.grad += ..., returns None to autograd
         else:
             gw = ConvWgrad.apply(x, gc, resample, scale)
     gb = ChannelSum.apply(gc) if (has_bias and ctx.needs_input_grad[bias_index] and _param_grads_wanted()) else None
@@ -399,8 +425,10 @@ class ConvLReLUPN(Function):
     def forward(ctx, x, weight, bias, resample, scale, slope, in_link=None, out_link=None):
         ctx.set_materialize_grads(False)
         x = _c(x)
-        y, rn = _run_conv(x, weight, bias, resample, scale, 1, slope)
+        kept = []
+        y, rn = _run_conv(x, weight, bias, resample, scale, 1, slope, keep_pooled=kept)
         ctx.save_for_backward(x, weight, y, rn)
+        ctx.pooled = kept[0] if kept else None        # (an intermediate of this node, not an input: held outside saved_tensors)
         ctx.has_bias = bias is not None
         ctx.cfg = (resample, scale, slope)
         ctx.n_in = 6 + (in_link is not None or out_link is not None) * 2
@@ -433,7 +461,7 @@ class ConvLReLUPN(Function):
             if gy is None:
                 gy, extra = (extra, None) if extra is not None else (torch.zeros_like(y), None)
             gc = LReLUPNBwd.apply(gy, gr, y, rn, slope, None, extra) if extra is not None else LReLUPNBwd.apply(gy, gr, y, rn, slope)
-        gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
+        gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias, pooled=ctx.pooled)
         return (gx, gw, gb) + pad
 
 

@@ -542,7 +542,74 @@ def test_persistent_conv_with_many_tiles_per_workgroup(ngan, case, conv_precisio
     assert worst < 2e-4, worst
 
 
-@pytest.mark.parametrize("case", [(2, 16, 32, 16, 16, 0), (1, 64, 64, 32, 32, 0), (2, 8, 8, 64, 64, 0), (1, 32, 64, 16, 32, 1), (2, 32, 32, 32, 16, 2)])
+WINO_SHAPES = [  # B, H, W, epilogue, out_mode, mode (0 forward weights, 1 input-gradient weights), resample (0 plain, 2 bilinear x2 on load)
+    (8, 128, 128, 0, 0, 0, 0), (8, 128, 128, 1, 0, 0, 0), (6, 100, 128, 1, 0, 1, 0), (1, 200, 328, 0, 0, 0, 0), (1, 200, 328, 1, 0, 1, 0),
+    (8, 128, 128, 2, 0, 1, 0), (8, 128, 128, 0, 1, 1, 0), (8, 128, 128, 2, 1, 1, 0), (2, 256, 256, 3, 0, 0, 0), (4, 256, 256, 1, 0, 0, 0),
+    (2, 128, 256, 0, 0, 0, 2), (2, 136, 296, 1, 0, 0, 2),
+]
+
+
+@pytest.mark.parametrize("kn", [(16, 16), (16, 32), (32, 16), (32, 32)])
+@pytest.mark.parametrize("shape", WINO_SHAPES)
+def test_winograd_kernels_against_fp64(ngan, shape, kn):
+    """The Winograd F(2x2, 3x3) kernels (precision code 4: conv3x3_tile / _persist for 16 -> 16, conv3x3_wino for the shapes with
+    a 32-channel side) through the C ABI against an fp64 evaluation of the WHOLE fused operator -- every epilogue and store mode,
+    whole and ragged tiles, forward and input-gradient weight orientation.  The reference applies LeakyReLU by itself: a bias of
+    +-12 per output channel keeps every pre-activation away from the kink (epilogues 1 and 3).  Promoted from tools/wino_check.py."""
+    B, H, W, epi, om, mode, res = shape
+    K, N = kn
+    C, ops = ngan._C, ngan.ops
+    prec = C.conv3x3_algorithm(B, H, W, K, N, res, 0)
+    if prec != 4:
+        assert (K, N) != (16, 16) and (res != 0 or W % 32), "a Winograd-eligible shape fell back to the direct form"
+        pytest.skip("the 32-channel Winograd kernel takes plain input on whole 32-pixel tiles")
+    torch.manual_seed(B + H + W + epi + om + K + 3 * N)
+    hin, win = (H // 2, W // 2) if res == 2 else (H, W)
+    x = torch.randn(B, hin, win, K)
+    w = torch.randn(N, K, 3, 3) if mode == 0 else torch.randn(K, N, 3, 3)          # mode 1: the weight of the conv being differentiated
+    scale = 1.3868 / np.sqrt(9 * K)
+    oh, ow = (2 * H, 2 * W) if om else (H, W)
+    sign = torch.tensor([1.0 if (c // 2) % 2 == 0 else -1.0 for c in range(N)])
+    bias = (12.0 * sign + 0.5 * torch.randn(N)) if epi in (1, 3) else (torch.randn(N) if epi == 0 and not om else None)
+    ay = torch.randn(B, oh, ow, N) if epi == 2 else (torch.randn(N) if epi == 3 else None)
+    arn = (torch.rand(B, oh, ow) + 0.5) if epi == 2 else None
+    y = torch.full((B, oh, ow, N), float("nan"), device=DEV)
+    rn = torch.full((B, H, W), float("nan"), device=DEV)
+    aout = torch.full((B, H, W), float("nan"), device=DEV) if epi == 3 else None
+    dv = lambda t: None if t is None else t.to(DEV)
+    C.call("ngan_conv3x3_fwd_ex", dv(x), ops._packed(dv(w), mode, scale, prec), dv(bias), y, rn if epi in (1, 3) else None, dv(ay), dv(arn), aout,
+           B, H, W, K, N, res, epi, om, SLOPE, 1e-8, prec, 0)
+    # fp64 reference of the same operator
+    wd = w.double() if mode == 0 else w.double().flip(2, 3).transpose(0, 1)
+    xin = x.double().permute(0, 3, 1, 2)
+    if res == 2:
+        xin = F.interpolate(xin, scale_factor=2, mode="bilinear", align_corners=False)
+    c = F.conv2d(xin * scale, wd, None if bias is None else bias.double(), padding=1)
+    if epi in (1, 3):
+        assert float(c.abs().min()) > 1.0
+        c = F.leaky_relu(c, SLOPE)
+        r = torch.sqrt(torch.mean(c * c, dim=1, keepdim=True) + 1e-8)
+        c = c / r
+        assert rel(rn.cpu(), r[:, 0]) < 2e-6
+    if om:
+        c = F.interpolate(c, scale_factor=2, mode="nearest") * 0.25                 # adjoint of the 2x2 average
+    if epi == 2:
+        a64, r64 = ay.double().permute(0, 3, 1, 2), arn.double().unsqueeze(1)
+        m = torch.where(a64 > 0, torch.ones_like(a64), torch.full_like(a64, SLOPE))
+        c = m * (c - a64 * torch.mean(c * a64, dim=1, keepdim=True)) / r64
+    got = nchw(y.cpu()).double()
+    assert not torch.isnan(got).any()
+    err_l2, err_max = float((got - c).norm() / c.norm()), float((got - c).abs().max() / c.abs().max())
+    assert err_l2 < 1e-6 and err_max < 2e-5, (err_l2, err_max)
+    if epi == 3:
+        t = torch.tanh(torch.sum(c * ay.double().view(1, N, 1, 1), dim=1))
+        assert float((aout.cpu().double() - t).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 16, 16, 0), (1, 64, 64, 32, 32, 0), (2, 8, 8, 64, 64, 0), (1, 32, 64, 16, 32, 1), (2, 32, 32, 32, 16, 2),
+                                  (4, 16, 16, 128, 128, 0),                                        # 128 channels (mid kernel, channels split over workgroups)
+                                  (2, 128, 256, 16, 16, 0), (2, 128, 256, 32, 32, 0), (2, 128, 256, 16, 32, 0), (2, 128, 256, 32, 16, 0),   # Winograd-eligible
+                                  (2, 128, 256, 16, 16, 2)])
 def test_conv_lrelu_pn_with_the_reference_own_leaky_mask(ngan, case, conv_precision):
     """The other conv tests hand the fp64 reference the kernel's own LeakyReLU sign pattern (`lrelu_like`), so a wrong sign rule in
     the kernel could hide.  Here the pre-activations are kept away from zero -- a bias of +-8 per output channel on top of a conv
