@@ -7,8 +7,11 @@ A "step" is one full iteration of the reference's inner loop (train.py:357-385):
 penalty, backward, Adam) then G step (loss, backward, Adam), n_critic = 1, at the 512x512 final stage (alpha = 1),
 batch 16 per GPU, synthetic reals 2*U[0,1)-1 already resident in HBM and unit-sphere latents drawn on the GPU.
 
-The headline `value` is measured in the reference's arithmetic: fp32 storage, fp32 accumulation and EXACT fp32 products
-(v_mfma_f32_16x16x4_f32; the reference computes in the default dtype, train.py:136-144), `dtype: "f32"`.  The faster split-bf16
+The headline `value` is measured in the reference's arithmetic: fp32 storage, fp32 accumulation and fp32 products on
+v_mfma_f32_16x16x4_f32 (the reference computes in the default dtype, train.py:136-144), `dtype: "f32"`.  The 16- and 32-channel
+layers on large images run in Winograd F(2x2, 3x3) form -- still fp32 throughout, but 16 products per 2x2 output tile and channel
+pair instead of 36, i.e. NOT the same products as the direct form; every such kernel instance is labelled in `conv_family` with
+the fraction of its algorithmic flops it actually executes on the matrix pipe (`executed_mfma_frac`).  The faster split-bf16
 convolution mode (3 bf16 MFMAs per fp32 product group, 16-bit-mantissa operands) is timed by the same protocol right afterwards
 and reported as the labelled sub-record `"bf16x3"` of the same JSON line, with the relative error it shows against the fp32 mode
 on identical weights and draws (`max_rel_err`).  It is never the headline.
@@ -151,7 +154,19 @@ def is_winograd_instance(name):
     """exact-fp32 kernels in Winograd F(2x2, 3x3) form: conv (last template argument PREC = 2) and weight gradient (WINO = 1)"""
     if "wgrad_f32_kernel" in name:
         return name.rstrip(">").endswith(", 1") and name.count(",") == 6
+    if "conv3x3_wino_kernel" in name:
+        return True
     return ("persist" in name or "tile_kernel" in name) and name.rstrip(">").endswith(", 2")
+
+
+def rank_report(rows):
+    """rows[r] = (ms per iteration on rank r's own clock, ms per iteration inside the critic exchange, ... the generator exchange):
+    the part of rank 0's JSON line that makes a multi-GPU run readable -- who was slow, and how long the collectives took"""
+    return {"ms_per_step": [round(r[0], 4) for r in rows], "ms_per_step_min": min(r[0] for r in rows), "ms_per_step_max": max(r[0] for r in rows),
+            "exchange_ms_per_step": {"critic": [round(r[1], 4) for r in rows], "generator": [round(r[2], 4) for r in rows]},
+            "exchange_timing": "HIP events on the communication stream around each gradient exchange (critic: one all-reduce; "
+                               "generator: the stem's factor all-gathers + the tail all-reduce; the local stem weight gradient "
+                               "formed from the gathered factors runs on the compute stream and is not in these numbers)"}
 
 
 def build_nets(pkg, res, alpha, device):
@@ -256,12 +271,22 @@ def run_mode(pkg, args, precision, device, world, rank, use_dist):
     fence()
     if probe is not None and not use_graph:
         pkg._C.set_probe(probe)
+    if use_dist:
+        trainer.comm_timing = []           # (tag, start event, end event) per gradient exchange, on the communication stream
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
     pkg._C.set_probe(None)
+    own_elapsed = elapsed
+    exchange_ms = None
+    if use_dist:
+        per = {}
+        for tag, e0, e1 in trainer.comm_timing:
+            per.setdefault(tag, []).append(e0.elapsed_time(e1))
+        exchange_ms = {tag: sum(v) / args.steps for tag, v in per.items()}      # ms per iteration spent inside each exchange
+        trainer.comm_timing = None
     probe_note = "HIP events around each launch during the timed steps"
     if probe is not None and use_graph:
         # kernels inside a replayed graph cannot be bracketed by events: run the same K steps once more, eagerly,
@@ -272,12 +297,19 @@ def run_mode(pkg, args, precision, device, world, rank, use_dist):
         fence()
         pkg._C.set_probe(None)
         probe_note = "HIP events around each launch, eager re-run of the timed steps right after the graph-replayed timing"
+    ranks = None
     if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what makes a first hardware scaling run readable: every rank's own clock and its time inside the two exchanges
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, exchange_ms.get("critic", 0.0), exchange_ms.get("generator", 0.0)],
+                            device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks = rank_report([r.tolist() for r in allr])
 
-    out = {"elapsed": elapsed, "launch": ("hip-graph replay" + (" (3 segments, eager gradient exchange between)" if use_dist else ""))
+    out = {"elapsed": elapsed, "ranks": ranks, "launch": ("hip-graph replay" + (" (3 segments, eager gradient exchange between)" if use_dist else ""))
            if use_graph else "eager", "roofline": None, "conv_family": None}
     if rank == 0 and probe is not None and probe.records:
         summ = probe.summary()
@@ -308,9 +340,20 @@ def run_mode(pkg, args, precision, device, world, rank, use_dist):
                                         "executed_mfma_frac": d["tflops"] * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS})
         tot_f = sum(v["flops"] for v in summ.values())
         tot_s = sum(v["seconds"] for v in summ.values())
+
+        def label(k, v):
+            e = {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
+                 "launches_per_step": v["launches"] / args.steps, "hbm_frac": round(v["gbs"] / PEAK_HBM_GBS, 3)}
+            if not is_split_bf16_instance(k):
+                e["mfma_frac"] = round(v["tflops"] / PEAK_FP32_MFMA_TFLOPS, 3)          # ALGORITHMIC flops against the fp32 MFMA peak
+                if is_winograd_instance(k):                                             # ... of which the Winograd forms execute 4/9
+                    e.update({"algorithm": "winograd_f2x2_3x3", "executed_mfma_frac": round(v["tflops"] * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS, 3)})
+            return e
         out["conv_family"] = {"tflops": tot_f / tot_s / 1e12, "seconds_per_step": tot_s / args.steps,
-                              "instances": {k: {"avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
-                                                "launches_per_step": v["launches"] / args.steps} for k, v in summ.items()}}
+                              # time-weighted over every probed conv launch (what "the dominant kernel" cannot say when the top
+                              # instances are within 20 % of each other)
+                              "frac_of_fp32_mfma_peak": (tot_f / tot_s / 1e12 / PEAK_FP32_MFMA_TFLOPS) if precision == "f32" else None,
+                              "instances": {k: label(k, v) for k, v in summ.items()}}
     del trainer, G, D, pool
     torch.cuda.empty_cache()
     return out
@@ -448,6 +491,8 @@ def main():
                "step_frac_of_fp32_mfma_peak": (value * w_alg / 1e12 / world / PEAK_FP32_MFMA_TFLOPS) if args.precision == "f32" else None,
                "step_algorithmic_gbs": value * e_alg * 4 / 1e9 / world,
                "roofline": head["roofline"], "conv_family": head["conv_family"]}
+        if head.get("ranks") is not None:
+            out["ranks"] = head["ranks"]
         if sub is not None:
             v2 = images / sub["elapsed"]
             out["bf16x3"] = {"label": "split-bf16 convolution mode (NOT the headline: 16-bit-mantissa operands, narrower than the reference's fp32)",

@@ -252,6 +252,23 @@ def _pooled(x):
     return _resample("ngan_pool2_fwd", x, (b, h2 // 2, w2 // 2, c), b, h2 // 2, w2 // 2, c)
 
 
+def _n_chunks(n):
+    """Output-channel counts one kernel launch takes are 16, 32, 64 and 128 (include/ngan.h); any other multiple of 16 -- the
+    reference's wide presets have 256-channel blocks, configs/config.py:87-98 -- is computed in chunks of those sizes, largest
+    first: [(first channel, count), ...]"""
+    out, c0 = [], 0
+    while n - c0 >= 128:
+        out.append((c0, 128))
+        c0 += 128
+    for size in (64, 32, 16):
+        if n - c0 >= size:
+            out.append((c0, size))
+            c0 += size
+    if c0 != n:
+        raise RuntimeError(f"conv3x3: channel count {n} is not a multiple of 16")
+    return out
+
+
 def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=None):
     """y (and rnorm) = epilogue(conv3x3(resample(x), scale*W) + bias); keep_pooled: a list that receives the pooled input copy
     when one was made (`_pool_first`)"""
@@ -266,6 +283,16 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=Non
         raise RuntimeError(f"conv3x3: input has {x.shape[3]} channels, weight expects {cin}")
     y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32)
     rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if epilogue else None
+    chunks = _n_chunks(cout)
+    if len(chunks) > 1:
+        # wide layer: one launch per output-channel chunk (each reads the whole input), then LeakyReLU -> PixelNorm over all the
+        # channels as a launch of its own (in place).  A compatibility path for the wide presets' small images, not a fast one.
+        for c0, n in chunks:
+            yc, _ = _run_conv(x, weight[c0:c0 + n], bias[c0:c0 + n] if bias is not None else None, resample, scale, 0, 0.0)
+            y[..., c0:c0 + n].copy_(yc)
+        if epilogue:
+            _C.call("ngan_lrelu_pixelnorm_fwd", y, None, y, rn, b * h * w, cout, float(slope), PIXELNORM_EPS)
+        return y, rn
     prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
     packed = _packed(weight, 0, scale, prec)
     _C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0, float(slope), PIXELNORM_EPS, prec,
@@ -282,10 +309,30 @@ def _run_dgrad(g, weight, resample, scale, link=None):
     cin = weight.shape[1]
     if cout != weight.shape[0]:
         raise RuntimeError(f"conv3x3 dgrad: gradient has {cout} channels, weight has {weight.shape[0]} outputs")
+    ay, arn, slope = (link.y, link.rn, float(link.slope)) if link is not None else (None, None, 0.0)
+    chunks = _n_chunks(cin)
+    if len(chunks) > 1:
+        # wide layer: the input gradient in chunks of its channels (the kernel's N), unfused; the producer's PixelNorm backward as
+        # a launch of its own over all the channels
+        oh, ow = (2 * h, 2 * w) if resample == RES_POOL2 else (h, w)
+        full = torch.empty((b, oh, ow, cin), device=g.device, dtype=torch.float32)
+        for c0, n in chunks:
+            full[..., c0:c0 + n].copy_(_run_dgrad(g, weight[:, c0:c0 + n], RES_POOL2 if resample == RES_POOL2 else RES_NONE, scale))
+        if resample == RES_UP2:
+            gx = torch.empty((b, h // 2, w // 2, cin), device=g.device, dtype=torch.float32)
+            if link is not None:
+                _C.call("ngan_up2_adjoint_pnbwd", full, ay, arn, gx, b, h // 2, w // 2, cin, slope)
+            else:
+                _C.call("ngan_up2_adjoint", full, gx, b, h // 2, w // 2, cin)
+            return gx
+        if link is not None:
+            if tuple(ay.shape) != tuple(full.shape):
+                raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(full.shape)}")
+            _C.call("ngan_lrelu_pixelnorm_bwd", full, None, ay, arn, full, b * oh * ow, cin, slope)
+        return full
     prec = _C.conv3x3_algorithm(b, h, w, cout, cin, 0, _conv_precision)
     packed = _packed(weight, 1, scale, prec)
     epi = EPI_PN_BWD if link is not None else EPI_NONE
-    ay, arn, slope = (link.y, link.rn, float(link.slope)) if link is not None else (None, None, 0.0)
     if resample == RES_POOL2:
         gx = torch.empty((b, 2 * h, 2 * w, cin), device=g.device, dtype=torch.float32)
         if link is not None and tuple(ay.shape) != tuple(gx.shape):

@@ -227,6 +227,7 @@ class PGGANTrainer:
         self.last_z_g = None
         # collectives of the RCCL backend run on a stream of their own (see _on_comm_stream); created on first need
         self._comm_stream = None
+        self.comm_timing = None     # bench.py: a list that receives (tag, start event, end event) of every gradient exchange
         if self.device.type == "cuda" and dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == "nccl":
             self._comm_stream = torch.cuda.Stream(device=self.device)
         self._graphs = {}          # input shape -> captured graphs of this stage (capture / replay)
@@ -275,7 +276,7 @@ class PGGANTrainer:
             return sample_latent_vec_device((batch, self.G.latent_dim), self.device)
         return sample_latent_vec((batch, self.G.latent_dim), device=self.device)
 
-    def _on_comm_stream(self, fn):
+    def _on_comm_stream(self, fn, tag="exchange"):
         """Run the collectives of `fn` on this trainer's communication stream, ordered after the work already queued on the current
         stream and before whatever the current stream does next.
 
@@ -290,23 +291,38 @@ class PGGANTrainer:
         communication stream -- no autograd node is created on it, no capture is begun on it, no captured stream waits on it -- so it
         can never be part of a capture and the watchdog may poll its events at any time.  (CPU tensors / the gloo rehearsal have no
         such event and run in line.)"""
+        timed = self.comm_timing is not None and self.device.type == "cuda"
         if self._comm_stream is None:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                self.comm_timing.append((tag, e0, e1))
+                return None
             return fn()
         cur = torch.cuda.current_stream()
         self._comm_stream.wait_stream(cur)
         with torch.cuda.stream(self._comm_stream):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             fn()
+            if timed:
+                e1.record()
+                self.comm_timing.append((tag, e0, e1))
         cur.wait_stream(self._comm_stream)
 
     def _exchange(self, flat):
         if flat is self.flat_g and self.stem is not None:
             # the stem occupies the head of G's flat buffer: gather its factors, all-reduce only the tail
-            self.stem.finish(self._on_comm_stream)
+            self.stem.finish(lambda fn: self._on_comm_stream(fn, "generator"))
             if self.world > 1 or self.force_exchange:
-                self._on_comm_stream(lambda: dist.all_reduce(flat.grad[self._stem_elems:], op=dist.ReduceOp.SUM, group=self.group))
+                self._on_comm_stream(lambda: dist.all_reduce(flat.grad[self._stem_elems:], op=dist.ReduceOp.SUM, group=self.group), "generator")
             return
         if self.world > 1 or self.force_exchange:
-            self._on_comm_stream(lambda: exchange_gradients(flat, self.world, self.group, force=self.force_exchange))
+            self._on_comm_stream(lambda: exchange_gradients(flat, self.world, self.group, force=self.force_exchange),
+                                 "critic" if flat is self.flat_d else "generator")
 
     def d_compute(self, real, z_d=None, z_gp=None, eps=None):
         """D half-step up to (and including) the backward pass: gradients end up in flat_d.grad."""

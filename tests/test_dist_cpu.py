@@ -1,6 +1,7 @@
 """World-size-2 data-parallel checks on the CPU (gloo): the flat-gradient exchange of the step driver, and the
 data-parallel equivalence the design relies on: 2 ranks x batch b with summed gradients scaled by 1/2
 == 1 rank x batch 2b.  The per-rank gradients come from the CPU oracle; the exchange is the product's code."""
+import json
 import os
 import socket
 import sys
@@ -118,6 +119,22 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"],
                          env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_bench_line_reports_every_rank_and_the_exchanges():
+    """With N > 1 rank 0's JSON line carries each rank's own ms / iteration (min / max) and the time inside the two gradient
+    exchanges, and every Winograd kernel instance is labelled with the share of its algorithmic flops it executes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rep = bench.rank_report([(7.61, 0.021, 0.093), (7.58, 0.020, 0.095), (7.90, 0.033, 0.101)])
+    assert rep["ms_per_step"] == [7.61, 7.58, 7.9] and rep["ms_per_step_min"] == 7.58 and rep["ms_per_step_max"] == 7.90
+    assert rep["exchange_ms_per_step"]["critic"] == [0.021, 0.02, 0.033] and len(rep["exchange_ms_per_step"]["generator"]) == 3
+    json.dumps(rep)
+    assert bench.is_winograd_instance("conv3x3_wino_kernel<2, 2, 8, 8, 1, 0>") and bench.is_winograd_instance("conv3x3_tile_kernel<1, 1, 1, 0, 2>")
+    assert bench.is_winograd_instance("wgrad_f32_kernel<1, 1, 0, 32, 4, 1, 1>") and not bench.is_winograd_instance("wgrad_f32_kernel<2, 2, 0, 16, 8, 0, 0>")
+    assert not bench.is_winograd_instance("conv3x3_mid_kernel<4, 2, 1, 2, 0, 0, 1, 0>") and not bench.is_split_bf16_instance("conv3x3_wino_kernel<2, 2, 8, 8, 1, 0>")
 
 
 def test_bench_parent_never_imports_torch():

@@ -150,9 +150,10 @@ def test_full_width_pins(ngan, name, conv_precision):
             # differently move it by up to 2.3e-3 in split-bf16 mode while every operator agrees with fp64 to < 1e-5
             # (tools/first_block_sensitivity.py prints the four arithmetic variants); exact-fp32 mode stays below 1.2e-4
             assert abs(got - cs[1]) < (4e-3 if k.startswith("ToIm") else 2e-3) * cs[1], ("G pre", k, got, cs[1])
-            # element-wise: 5e-3 of the tensor's max-norm (init-state generator gradients are ~1e-5 and sums over 2M pixels whose
-            # LeakyReLU ties fall either way; measured worst over C1-C5 in exact fp32: 2.2e-3, layers.8.1.weight of C5)
-            check_slices(fix, "Ggrad_pre/" + k, p.grad.cpu().numpy(), 5e-3)
+            # element-wise, of the tensor's max-norm: 3e-3 in exact fp32 (measured worst over C1-C5: 2.2e-3, layers.8.1.weight of C5;
+            # init-state generator gradients are ~1e-5 and sums over 2M pixels whose LeakyReLU ties fall either way), 5e-3 in the
+            # split-bf16 mode.  DESIGN.md section 2 quotes these two numbers.
+            check_slices(fix, "Ggrad_pre/" + k, p.grad.cpu().numpy(), 3e-3 if conv_precision == "f32" else 5e-3)
     G.zero_grad()
     D.zero_grad()
     scal, norms, dgrads, ggrads = run_step_losses(ngan, G, D, fx)
@@ -170,7 +171,7 @@ def test_full_width_pins(ngan, name, conv_precision):
     # step): the generator gradients seen through the updated critic scatter by 1e-3 .. 1.1e-2 between arithmetic variants
     # whose critic gradients all agree with the reference to 1e-4 (tools/c2_sensitivity.py prints the four variants: exact
     # fp32 / split-bf16, fused / unfused backward).  2e-2 bounds that amplification; the tight statement about the
-    # generator's gradients is the pre-update check above (2e-3).
+    # generator's gradients is the pre-update check above (3e-3 / 5e-3).
     for k, g in ggrads.items():
         cs = fix["cs/Ggrad/" + k]
         assert abs(float(np.abs(g.astype(np.float64)).sum()) - cs[1]) < 2e-2 * cs[1], ("G", k)
@@ -179,7 +180,10 @@ def test_full_width_pins(ngan, name, conv_precision):
 @pytest.mark.parametrize("n_colors,res,alpha,widths", [(3, 16, 0.5, None), (3, 16, 1.0, None), (1, 32, 1.0, None),
                                                        # widths that are not multiples of 16: the reference's presets 0004-0006 end in
                                                        # 8-channel blocks (configs/config.py:86-92); zero-padded contraction path
-                                                       (1, 16, 0.5, ([32, 8], [8, 32])), (1, 32, 1.0, ([16, 8, 8], [8, 8, 16]))])
+                                                       (1, 16, 0.5, ([32, 8], [8, 32])), (1, 32, 1.0, ([16, 8, 8], [8, 8, 16])),
+                                                       # wide blocks shaped like the presets 0006-0008 (configs/config.py:90-98): more
+                                                       # than 128 channels per conv run as output-channel chunks (ops._n_chunks)
+                                                       (1, 32, 1.0, ([256, 128, 64], [64, 128, 256])), (1, 16, 0.5, ([256, 128], [128, 256]))])
 def test_losses_and_gradients_match_oracle_on_the_fly(ngan, n_colors, res, alpha, widths, conv_precision):
     """Configurations the committed fixtures do not hold (RGB images: the reference's N_colors constructor argument; a 32x32 stable
     stage of a three-block net): one critic loss + gradient penalty + generator loss against the CPU oracle evaluated here on the
