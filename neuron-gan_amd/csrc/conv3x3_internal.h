@@ -24,6 +24,11 @@ inline int diag_int(const char* name, int dflt) { const char* e = getenv(name); 
 #define NGAN_DIAG_INT(name, dflt) (dflt)
 #endif
 
+// workgroups of the 16 -> 16 Winograd instances the register allocation makes room for per CU (waves per SIMD; build-time knob)
+#ifndef NGAN_WINO16_WPE
+#define NGAN_WINO16_WPE 2
+#endif
+
 namespace ngan {
 // launchers exported by the kernel files (template instance chosen at run time from the arguments)
 int conv3x3_tile_launch(const ConvArgs& a, int mtw, int kg, int epilogue, int out_mode, int tprec, hipStream_t s);                  // conv3x3_tile.hip

@@ -22,7 +22,7 @@ namespace {
 // the issue time of the instructions removed (161 / 143 / 132 us; the MFMAs alone need 123).
 // ---------------------------------------------------------------------------------------------------------
 template <int MTW, int KG, int RES, int EPI, int OUTMODE, int PREC>
-__global__ __launch_bounds__(256, PREC == 2 ? 2 : (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_persist_kernel(ConvArgs a, int n_tiles) {
     // PREC: 0 exact fp32 (direct), 1 split bf16, 2 exact fp32 by Winograd F(2x2, 3x3) (16 -> 16; the MFMA section of conv3x3_tile_kernel)
     constexpr bool BF = PREC == 1, WINO = PREC == 2;
     static_assert(!WINO || (MTW == 1 && KG == 1), "the Winograd form is built for the 16 -> 16 layers");
