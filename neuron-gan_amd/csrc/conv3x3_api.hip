@@ -8,7 +8,7 @@
 static bool wino_eligible(int B, int H, int W, int K, int N, int resample) {
     if (!NGAN_DIAG_FLAG("NGAN_WINOGRAD", true) || resample == NGAN_RESAMPLE_POOL2 || !persist_eligible(B, H, W, K, N, resample)) return false;
     if (K == 16 && N == 16) return true;
-    return NGAN_DIAG_FLAG("NGAN_WINOGRAD32", true) && resample == NGAN_RESAMPLE_NONE && W % 32 == 0;
+    return NGAN_DIAG_FLAG("NGAN_WINOGRAD32", true) && W % 32 == 0;
 }
 
 extern "C" int ngan_conv3x3_algorithm(int B, int H, int W, int K, int N, int resample, int precision) {
@@ -75,8 +75,9 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
         }
         // precision code 4 = the Winograd form (16 -> 16: checked by the precision test above) = the kernels' PREC parameter 2
         const int tprec = precision == 4 ? 2 : precision;
-        if (tprec == 2 && (K == 32 || N == 32))          // (plain input on whole tiles: wino_eligible)
-            return ngan::conv3x3_wino_launch(a, N / 16, K / 16, epilogue, out_mode, s);
+        // Winograd form in conv3x3_wino.hip: the shapes with a 32-channel side, and every bilinear-input shape on whole tiles
+        if (tprec == 2 && W % 32 == 0 && (K == 32 || N == 32 || (resample == NGAN_RESAMPLE_UP2 && NGAN_DIAG_FLAG("NGAN_WINOGRAD_UP2", true))))
+            return ngan::conv3x3_wino_launch(a, N / 16, K / 16, resample, epilogue, out_mode, s);
         if (resample == 0 && NGAN_DIAG_FLAG("NGAN_TILE_KERNEL", true) && W % 32 == 0)      // plain input, whole tiles along x
             return ngan::conv3x3_tile_launch(a, N / 16, K / 16, epilogue, out_mode, tprec, s);
         return ngan::conv3x3_persist_launch(a, N / 16, K / 16, resample, epilogue, out_mode, tprec, s);
@@ -118,9 +119,9 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     const int ci = pick_cfg(mti, B, H, W);
     if (precision == 3)
         snprintf(buf, len, "conv3x3_up2f_kernel<%d, %d>", K / 16, epilogue);
-    else if (precision == 4 && (K == 32 || N == 32))
-        snprintf(buf, len, "conv3x3_wino_kernel<%d, %d, %d, %d, %d, %d>", K / 16, N / 16, ngan::conv3x3_wino_tile_rows(N / 16, K / 16),
-                 (K == 16) ? 4 : 8, (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode);
+    else if (precision == 4 && W % 32 == 0 && (K == 32 || N == 32 || (resample == NGAN_RESAMPLE_UP2 && NGAN_DIAG_FLAG("NGAN_WINOGRAD_UP2", true))))
+        snprintf(buf, len, "conv3x3_wino_kernel<%d, %d, %d, %d, %d, %d, %d>", K / 16, N / 16, ngan::conv3x3_wino_tile_rows(N / 16, K / 16),
+                 (K == 16) ? 4 : 8, resample, (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue, out_mode);
     else if (N <= 32 && K <= 32 && resample != NGAN_RESAMPLE_POOL2 && ci == 0) {
         if ((out_mode || resample == 0) && NGAN_DIAG_FLAG("NGAN_TILE_KERNEL", true) && W % 32 == 0)
             snprintf(buf, len, "conv3x3_tile_kernel<%d, %d, %d, %d, %d>", N / 16, K / 16, (out_mode && epilogue != EPI_PN_BWD) ? 0 : epilogue,

@@ -33,7 +33,7 @@ namespace ngan {
 // launchers exported by the kernel files (template instance chosen at run time from the arguments)
 int conv3x3_tile_launch(const ConvArgs& a, int mtw, int kg, int epilogue, int out_mode, int tprec, hipStream_t s);                  // conv3x3_tile.hip
 int conv3x3_persist_launch(const ConvArgs& a, int mtw, int kg, int resample, int epilogue, int out_mode, int tprec, hipStream_t s); // conv3x3_persist.hip
-int conv3x3_wino_launch(const ConvArgs& a, int mtw, int kg, int epilogue, int out_mode, hipStream_t s);                              // conv3x3_wino.hip
+int conv3x3_wino_launch(const ConvArgs& a, int mtw, int kg, int resample, int epilogue, int out_mode, hipStream_t s);                              // conv3x3_wino.hip
 int conv3x3_wino_tile_rows(int mtw, int kg);
 int conv3x3_up2f_launch(const ConvArgs& a, int epilogue, hipStream_t s);                                                            // conv3x3_up2f.hip
 int conv3x3_up2_border_launch(const ConvArgs& a, int epilogue, hipStream_t s);

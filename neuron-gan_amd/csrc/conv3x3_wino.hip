@@ -26,16 +26,30 @@
 
 namespace {
 
-template <int KG, int MT, int ROWS, int NWAVES, int EPI, int OUTMODE>
+template <int KG, int MT, int ROWS, int NWAVES, int RES, int EPI, int OUTMODE>
 __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a, int n_tiles) {
+    // RES = 2: the conv input is bilinear_x2(x) (align_corners = False), x at half the resolution.  Nothing is expanded: a 2x2 output
+    // tile at even coordinates (Y0, X0) sees hi-res rows Y0-1 .. Y0+2, which are fixed blends of the THREE low-res rows i-1, i, i+1
+    // (i = Y0 / 2):  d = E L E^T,  E = [.75 .25 0; .25 .75 0; 0 .75 .25; 0 .25 .75],  so  B^T d B = (B^T E) L (B^T E)^T  is computed
+    // straight from the lane's 3x3 low-res patch (9 LDS reads per channel group instead of 16, a 6 x 18 patch in LDS instead of a
+    // 10 x 34 tile, no expansion pass and no barrier for it).  The conv's zero padding lives in OUTPUT space: hi-res row -1 / H
+    // (column -1 / W) is zero, not a blend -- the rows of E that produce it are switched off by a factor z in {0, 1} folded into the
+    // blend coefficients (rows: per wave; columns: per lane).  The bilinear taps' own edge rule (clamped low-res index) is applied
+    // by the patch loads.
+    static_assert(RES == 0 || (RES == 2 && (EPI == EPI_NONE || EPI == EPI_LRELU_PN) && OUTMODE == 0), "bilinear input: forward convs only");
+    constexpr bool UP = RES == 2;
     constexpr int NT = NWAVES * 64, TR = ROWS / 2, NS = NWAVES / TR, MTW = MT / NS;   // tile rows; waves per tile row; n-tiles per wave
     static_assert(NWAVES % TR == 0 && (NS == 1 || NS == 2) && MT % NS == 0, "wave split");
-    constexpr int HH_ = ROWS + 2, LP = 40, PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int HH_ = ROWS + 2, LP = 40;
+    constexpr int PH = ROWS / 2 + 2, PW = 18, PLP = 24;           // low-res patch: rows, columns used, row pitch (a multiple of 8)
+    constexpr int PLANE = UP ? PH * PLP * 16 : HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
     constexpr int W_ELEMS = 16 * KG * MT * 256;
     constexpr int K = KG * 16, N = MT * 16, PGW = 4;
-    constexpr int NL = KG * HH_ * 128 / NT, NST = NL + 1;        // interior loads per thread (+ one load for the two halo columns)
+    constexpr int N_SRC = KG * PH * PW * 4;                       // patch float4s (bilinear)
+    constexpr int NL = UP ? (N_SRC + NT - 1) / NT : KG * HH_ * 128 / NT;   // loads per thread (plain: interior loads, + one for the two halo columns)
+    constexpr int NST = NL + 1;
     constexpr int N_HALO = KG * 2 * HH_ * 4;
-    static_assert((KG * HH_ * 128) % NT == 0 && N_HALO <= NT, "staging layout");
+    static_assert(UP || ((KG * HH_ * 128) % NT == 0 && N_HALO <= NT), "staging layout");
     constexpr unsigned OOB = 0xFFFFFFF0u;
     constexpr bool PNB = EPI == EPI_PN_BWD;
     constexpr int NSUB = (PNB && OUTMODE) ? 4 : 1;                // per-pixel sums a wave contributes per pixel group
@@ -56,25 +70,37 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
     int t = run.t;
     const int t_end = run.t_end;
 
-    // LDS image: one plane per 16-channel group; in a row, even and odd columns sit in separate halves (a lane reads columns
-    // 2p + b: position p + const), quads rotated by the column position as in the direct form -- conflict-free ds_read_b128
+    // LDS image (plain input): one plane per 16-channel group; in a row, even and odd columns sit in separate halves (a lane reads
+    // columns 2p + b: position p + const), quads rotated by the column position as in the direct form -- conflict-free ds_read_b128.
+    // Bilinear input: the low-res patch, [group][row][column] with the same quad rotation (a lane reads columns p + j)
     auto lds_slot = [&](int g, int c4, int ty, int tx) {
-        const int pos = (tx >> 1) + (tx & 1) * (LP / 2);
-        return g * PLANE + (ty * LP + pos) * 16 + ((c4 ^ (((pos >> 2) & 1) << 1)) << 2);
+        const int pos = UP ? tx : (tx >> 1) + (tx & 1) * (LP / 2);
+        return g * PLANE + (ty * (UP ? PLP : LP) + pos) * 16 + ((c4 ^ (((pos >> 2) & 1) << 1)) << 2);
     };
     // ---- tile-invariant staging constants: byte offset from the halo origin (y0 - 1, x0 - 1), LDS float index ----
     unsigned s_voff[NST];
     int s_lds[NST];
+    int h_bits = 8;                               // halo load: 1 = left column, 2 = right column, 4 = top row, 8 = unused lane
+    int s_dyx[UP ? NL : 1];                       // bilinear: patch cell (row in the high half, column in the low half) of load i
+    if (UP) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int e = tid + i * NT;
-        const int g = e / (HH_ * 128), r = e % (HH_ * 128);
-        const int c4 = r & 3, pix = r >> 2, ty = pix >> 5, tx = (pix & 31) + 1;
-        s_voff[i] = (unsigned)(((ty * a.W + tx) * K + g * 16 + c4 * 4) * 4);
-        s_lds[i] = lds_slot(g, c4, ty, tx);
-    }
-    int h_bits;                                   // halo load: 1 = left column, 2 = right column, 4 = top row, 8 = unused lane
-    {
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * NT;
+            const int c4 = e & 3, pp = (e >> 2) % (PH * PW), g = (e >> 2) / (PH * PW);
+            s_dyx[UP ? i : 0] = ((pp / PW) << 16) | (pp % PW);
+            s_voff[i] = (unsigned)((g * 16 + c4 * 4) * 4);
+            s_lds[i] = lds_slot(g < KG ? g : 0, c4, pp / PW, pp % PW);
+        }
+        s_voff[NL] = 0; s_lds[NL] = 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * NT;
+            const int g = e / (HH_ * 128), r = e % (HH_ * 128);
+            const int c4 = r & 3, pix = r >> 2, ty = pix >> 5, tx = (pix & 31) + 1;
+            s_voff[i] = (unsigned)(((ty * a.W + tx) * K + g * 16 + c4 * 4) * 4);
+            s_lds[i] = lds_slot(g, c4, ty, tx);
+        }
         const int c4 = tid & 3, r = (tid >> 2) % HH_, sg = (tid >> 2) / HH_, side = sg & 1, g = sg >> 1;
         const bool used = tid < N_HALO;
         const int tx = side ? 33 : 0;
@@ -82,10 +108,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         s_lds[NL] = lds_slot(used ? g : 0, c4, used ? r : 0, tx);
         h_bits = used ? ((side ? 2 : 1) | (r == 0 ? 4 : 0)) : 8;
     }
-    int wrd[4];                                    // LDS float index of column 2p + b of a tile row, channel quad q
+    int wrd[4];                                    // LDS float index of column 2p + b of a tile row (bilinear: patch column p + b), channel quad q
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int pos = p + (b >> 1) + (b & 1) * (LP / 2);
+        const int pos = UP ? p + b : p + (b >> 1) + (b & 1) * (LP / 2);
         wrd[b] = pos * 16 + ((q ^ (((pos >> 2) & 1) << 1)) << 2);
     }
     // ---- tile-invariant epilogue constants: this lane's output byte offsets from the tile origin; pixel group pg = pixel
@@ -108,11 +134,24 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         b = tt / a.tiles_y;
         y0 = tyi * ROWS; x0 = txi * 32;
     };
-    const unsigned img_bytes = (unsigned)(a.H * a.W * K) * 4u;
+    const int lh = a.H >> 1, lw = a.W >> 1;          // low-res extent (bilinear)
+    const unsigned img_bytes = (unsigned)((UP ? lh * lw : a.H * a.W) * K) * 4u;
     float4 stg[NST];
     auto issue = [&](int tt) {
         int b, y0, x0;
         decode(tt, b, y0, x0);
+        if (UP) {
+            // the 6 x 18 low-res patch of the tile, loaded with CLAMPED coordinates: the bilinear taps' edge rule
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * lh * lw * K), 0, img_bytes, 0x00020000);
+            const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int ly = min(max(ly0 + (s_dyx[UP ? i : 0] >> 16), 0), lh - 1), lx = min(max(lx0 + (s_dyx[UP ? i : 0] & 0xffff), 0), lw - 1);
+                const unsigned off = (tid + i * NT < N_SRC) ? (unsigned)((ly * lw + lx) * K * 4) + s_voff[i] : OOB;
+                stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+            }
+            return;
+        }
         const int soff = ((y0 - 1) * a.W + (x0 - 1)) * K * 4;                 // negative on the top row / for the first tile
         const char* base = reinterpret_cast<const char*>(a.x + (long)b * a.H * a.W * K) + soff;
         const unsigned nrec = img_bytes - (unsigned)soff;                     // bytes from `base` to the end of the image
@@ -162,10 +201,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         int b, y0, x0;
         decode(t, b, y0, x0);
         __syncthreads();   // previous tile's MFMAs have finished reading `tile` (and its exchange buffers have been read)
+        if (UP) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) st4(&tile[s_lds[i]], stg[i]);
-        pin_registers(stg[NL]);     // every wave awaits the halo load here (the waves that store nothing would carry it, un-awaited, into the next issue)
-        if (tid < N_HALO) st4(&tile[s_lds[NL]], stg[NL]);
+            for (int i = 0; i < NL; ++i) {
+                pin_registers(stg[i]);          // (awaited by every lane, also those past the end of the patch)
+                if (tid + i * NT < N_SRC) st4(&tile[s_lds[i]], stg[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) st4(&tile[s_lds[i]], stg[i]);
+            pin_registers(stg[NL]);     // every wave awaits the halo load here (the waves that store nothing would carry it, un-awaited, into the next issue)
+            if (tid < N_HALO) st4(&tile[s_lds[NL]], stg[NL]);
+        }
         __syncthreads();
         const int tn = t + run.step;
         if (tn < t_end) issue(tn);   // in flight while this tile is computed
@@ -189,15 +236,45 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         // ---- Winograd section: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], A^T = [1 1 1 0; 0 1 -1 -1]; transforms on register
         // pairs (v_pk_add_f32 / v_pk_fma_f32), G g G^T done by the packing kernel (layout [position][n-tile][k-group][lane][4]) ----
         const f32x2 m1 = opaque_minus_one();
-        f32p bd[KG][4][4];                           // B^T d: rows transformed, columns still in pixel space
+        f32p bd[KG][4][UP ? 3 : 4];                  // B^T d: rows transformed, columns still in pixel space (bilinear: in low-res space)
+        // bilinear: blend coefficients of the row / column transforms  t0 = a0 x0 + b0 x1 - x2/4,  t1 = (x0 + x2)/4 + 1.5 x1,
+        // t2 = (x2 - x0)/4,  t3 = x0/4 + b3 x1 + c3 x2  (= B^T E with hi-res row -1 switched off by zt, row H by zb; see the top)
+        f32x2 ra0, rb0, rb3, rc3, ca0, cb0, cb3, cc3;
+        const f32x2 quarter2 = {0.25f, 0.25f}, c15 = {1.5f, 1.5f};
+        if (UP) {
+            const float zt = (y0 + 2 * tr > 0) ? 1.f : 0.f, zb = (y0 + 2 * tr + 2 < a.H) ? 1.f : 0.f;
+            const float zl = (x0 + 2 * p > 0) ? 1.f : 0.f, zr = (x0 + 2 * p + 2 < a.W) ? 1.f : 0.f;
+            const float a0 = 0.75f * zt, b0 = 0.25f * zt - 0.75f, b3 = 0.75f - 0.25f * zb, c3 = -0.75f * zb;
+            const float a0c = 0.75f * zl, b0c = 0.25f * zl - 0.75f, b3c = 0.75f - 0.25f * zr, c3c = -0.75f * zr;
+            ra0 = (f32x2){a0, a0}; rb0 = (f32x2){b0, b0}; rb3 = (f32x2){b3, b3}; rc3 = (f32x2){c3, c3};
+            ca0 = (f32x2){a0c, a0c}; cb0 = (f32x2){b0c, b0c}; cb3 = (f32x2){b3c, b3c}; cc3 = (f32x2){c3c, c3c};
+        }
+        auto pmul = [](f32p x, f32x2 c) { return f32p{x.l * c, x.h * c}; };
+        auto pfma = [](f32p x, f32x2 c, f32p y) { return f32p{__builtin_elementwise_fma(x.l, c, y.l), __builtin_elementwise_fma(x.h, c, y.h)}; };
+        // the four transformed values of three samples x0, x1, x2 (one dimension of (B^T E) L (B^T E)^T)
+        auto up_t0 = [&](f32p x0, f32p x1, f32p x2, f32x2 ca, f32x2 cb) { return pfma(x0, ca, pfma(x1, cb, pmul(x2, -quarter2))); };
+        auto up_t1 = [&](f32p x0, f32p x1, f32p x2) { return pfma(x1, c15, pmul(x0 + x2, quarter2)); };
+        auto up_t2 = [&](f32p x0, f32p x2) { return pmul(psub(x2, x0, m1), quarter2); };
+        auto up_t3 = [&](f32p x0, f32p x1, f32p x2, f32x2 cb, f32x2 cc) { return pfma(x0, quarter2, pfma(x1, cb, pmul(x2, cc))); };
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
+            if (UP) {
+                const float* prow = tile + g * PLANE + tr * (PLP * 16);        // patch rows tr, tr + 1, tr + 2 = low-res rows i - 1, i, i + 1
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32p l0 = pk2(*reinterpret_cast<const f32x4*>(prow + 0 * PLP * 16 + wrd[j])), l1 = pk2(*reinterpret_cast<const f32x4*>(prow + 1 * PLP * 16 + wrd[j]));
+                    const f32p l2 = pk2(*reinterpret_cast<const f32x4*>(prow + 2 * PLP * 16 + wrd[j]));
+                    bd[g][0][UP ? j : 0] = up_t0(l0, l1, l2, ra0, rb0); bd[g][1][UP ? j : 0] = up_t1(l0, l1, l2);
+                    bd[g][2][UP ? j : 0] = up_t2(l0, l2); bd[g][3][UP ? j : 0] = up_t3(l0, l1, l2, rb3, rc3);
+                }
+                continue;
+            }
             const float* trow = tile + g * PLANE + (2 * tr) * (LP * 16);
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
                 const f32p d0 = pk2(*reinterpret_cast<const f32x4*>(trow + 0 * LP * 16 + wrd[bb])), d1 = pk2(*reinterpret_cast<const f32x4*>(trow + 1 * LP * 16 + wrd[bb]));
                 const f32p d2 = pk2(*reinterpret_cast<const f32x4*>(trow + 2 * LP * 16 + wrd[bb])), d3 = pk2(*reinterpret_cast<const f32x4*>(trow + 3 * LP * 16 + wrd[bb]));
-                bd[g][0][bb] = psub(d0, d2, m1); bd[g][1][bb] = d1 + d2; bd[g][2][bb] = psub(d2, d1, m1); bd[g][3][bb] = psub(d1, d3, m1);
+                bd[g][0][UP ? 0 : bb] = psub(d0, d2, m1); bd[g][1][UP ? 0 : bb] = d1 + d2; bd[g][2][UP ? 0 : bb] = psub(d2, d1, m1); bd[g][3][UP ? 0 : bb] = psub(d1, d3, m1);
             }
         }
         f32p accp[PGW][MTW];                         // outputs: pixel group (row a, column b) of the 2x2 tile = a * 2 + b
@@ -212,9 +289,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
             for (int g = 0; g < KG; ++g) {
                 f32p vv[4];                          // (B^T d B)[u][v]
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    vv[u] = v == 0 ? psub(bd[g][u][0], bd[g][u][2], m1) : v == 1 ? bd[g][u][1] + bd[g][u][2]
-                          : v == 2 ? psub(bd[g][u][2], bd[g][u][1], m1) : psub(bd[g][u][1], bd[g][u][3], m1);
+                for (int u = 0; u < 4; ++u) {
+                    if (UP)
+                        vv[u] = v == 0 ? up_t0(bd[g][u][0], bd[g][u][1], bd[g][u][2], ca0, cb0) : v == 1 ? up_t1(bd[g][u][0], bd[g][u][1], bd[g][u][2])
+                              : v == 2 ? up_t2(bd[g][u][0], bd[g][u][2]) : up_t3(bd[g][u][0], bd[g][u][1], bd[g][u][2], cb3, cc3);
+                    else
+                        vv[u] = v == 0 ? psub(bd[g][u][0], bd[g][u][2], m1) : v == 1 ? bd[g][u][1] + bd[g][u][2]
+                              : v == 2 ? psub(bd[g][u][2], bd[g][u][1], m1) : psub(bd[g][u][1], bd[g][u][UP ? 0 : 3], m1);
+                }
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
                     f32x4 uu[4];
@@ -383,7 +465,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
     }
 }
 
-template <int KG, int MT, int ROWS, int NWAVES, int EPI, int OUTMODE>
+template <int KG, int MT, int ROWS, int NWAVES, int RES, int EPI, int OUTMODE>
 int launch_wino(ConvArgs a, hipStream_t s) {
     a.tiles_x = a.W / 32;
     a.tiles_y = ngan::ceil_div(a.H, ROWS);
@@ -391,29 +473,34 @@ int launch_wino(ConvArgs a, hipStream_t s) {
     static int per_cu = 0;
     if (per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_wino_kernel<KG, MT, ROWS, NWAVES, EPI, OUTMODE>, NWAVES * 64, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_wino_kernel<KG, MT, ROWS, NWAVES, RES, EPI, OUTMODE>, NWAVES * 64, 0) != hipSuccess || n < 1) n = 1;
         per_cu = n > 4 ? 4 : n;
     }
     const int grid = persistent_grid(n_tiles, 256 * per_cu);
-    hipLaunchKernelGGL((conv3x3_wino_kernel<KG, MT, ROWS, NWAVES, EPI, OUTMODE>), dim3(grid), dim3(NWAVES * 64), 0, s, a, n_tiles);
+    hipLaunchKernelGGL((conv3x3_wino_kernel<KG, MT, ROWS, NWAVES, RES, EPI, OUTMODE>), dim3(grid), dim3(NWAVES * 64), 0, s, a, n_tiles);
     return ngan::launch_status("ngan_conv3x3_fwd(winograd)");
 }
 
 template <int KG, int MT, int ROWS, int NWAVES>
-int dispatch_wino(const ConvArgs& a, int epi, int outmode, hipStream_t s) {
-    if (epi == EPI_PN_BWD) return outmode == 1 ? launch_wino<KG, MT, ROWS, NWAVES, EPI_PN_BWD, 1>(a, s) : launch_wino<KG, MT, ROWS, NWAVES, EPI_PN_BWD, 0>(a, s);
-    if (epi == EPI_TO_IMAGE) return launch_wino<KG, MT, ROWS, NWAVES, EPI_TO_IMAGE, 0>(a, s);
-    if (outmode == 1) return launch_wino<KG, MT, ROWS, NWAVES, EPI_NONE, 1>(a, s);
-    return epi ? launch_wino<KG, MT, ROWS, NWAVES, EPI_LRELU_PN, 0>(a, s) : launch_wino<KG, MT, ROWS, NWAVES, EPI_NONE, 0>(a, s);
+int dispatch_wino(const ConvArgs& a, int res, int epi, int outmode, hipStream_t s) {
+    if (res == NGAN_RESAMPLE_UP2) return epi ? launch_wino<KG, MT, ROWS, NWAVES, 2, EPI_LRELU_PN, 0>(a, s) : launch_wino<KG, MT, ROWS, NWAVES, 2, EPI_NONE, 0>(a, s);
+    if constexpr (KG * MT > 1) {      // (the plain 16 -> 16 form is conv3x3_tile_kernel's)
+        if (epi == EPI_PN_BWD) return outmode == 1 ? launch_wino<KG, MT, ROWS, NWAVES, 0, EPI_PN_BWD, 1>(a, s) : launch_wino<KG, MT, ROWS, NWAVES, 0, EPI_PN_BWD, 0>(a, s);
+        if (epi == EPI_TO_IMAGE) return launch_wino<KG, MT, ROWS, NWAVES, 0, EPI_TO_IMAGE, 0>(a, s);
+        if (outmode == 1) return launch_wino<KG, MT, ROWS, NWAVES, 0, EPI_NONE, 1>(a, s);
+        return epi ? launch_wino<KG, MT, ROWS, NWAVES, 0, EPI_LRELU_PN, 0>(a, s) : launch_wino<KG, MT, ROWS, NWAVES, 0, EPI_NONE, 0>(a, s);
+    }
+    return NGAN_ERR_ARG;
 }
 
 }  // namespace
 
 int ngan::conv3x3_wino_tile_rows(int mtw, int kg) { return (kg == 2 && mtw == 1) ? 16 : 8; }
 
-// plain input, a.W % 32 == 0, (mtw, kg) in {(2, 2), (1, 2), (2, 1)} (the caller checks)
-int ngan::conv3x3_wino_launch(const ConvArgs& a, int mtw, int kg, int epilogue, int out_mode, hipStream_t s) {
-    if (kg == 2 && mtw == 2) return dispatch_wino<2, 2, 8, 8>(a, epilogue, out_mode, s);
-    if (kg == 2) return dispatch_wino<2, 1, 16, 8>(a, epilogue, out_mode, s);
-    return dispatch_wino<1, 2, 8, 4>(a, epilogue, out_mode, s);
+// a.W % 32 == 0; plain input: (mtw, kg) in {(2, 2), (1, 2), (2, 1)}; bilinear input (epilogues 0 / 1): also (1, 1)  (the caller checks)
+int ngan::conv3x3_wino_launch(const ConvArgs& a, int mtw, int kg, int resample, int epilogue, int out_mode, hipStream_t s) {
+    if (kg == 2 && mtw == 2) return dispatch_wino<2, 2, 8, 8>(a, resample, epilogue, out_mode, s);
+    if (kg == 2) return dispatch_wino<2, 1, 16, 8>(a, resample, epilogue, out_mode, s);
+    if (mtw == 2) return dispatch_wino<1, 2, 8, 4>(a, resample, epilogue, out_mode, s);
+    return dispatch_wino<1, 1, 8, 4>(a, resample, epilogue, out_mode, s);
 }

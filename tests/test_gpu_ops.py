@@ -545,7 +545,7 @@ def test_persistent_conv_with_many_tiles_per_workgroup(ngan, case, conv_precisio
 WINO_SHAPES = [  # B, H, W, epilogue, out_mode, mode (0 forward weights, 1 input-gradient weights), resample (0 plain, 2 bilinear x2 on load)
     (8, 128, 128, 0, 0, 0, 0), (8, 128, 128, 1, 0, 0, 0), (6, 100, 128, 1, 0, 1, 0), (1, 200, 328, 0, 0, 0, 0), (1, 200, 328, 1, 0, 1, 0),
     (8, 128, 128, 2, 0, 1, 0), (8, 128, 128, 0, 1, 1, 0), (8, 128, 128, 2, 1, 1, 0), (2, 256, 256, 3, 0, 0, 0), (4, 256, 256, 1, 0, 0, 0),
-    (2, 128, 256, 0, 0, 0, 2), (2, 136, 296, 1, 0, 0, 2),
+    (2, 128, 256, 0, 0, 0, 2), (2, 136, 296, 1, 0, 0, 2), (2, 128, 256, 1, 0, 0, 2), (3, 136, 256, 1, 0, 0, 2), (16, 64, 64, 0, 0, 0, 2),
 ]
 
 
@@ -561,8 +561,8 @@ def test_winograd_kernels_against_fp64(ngan, shape, kn):
     C, ops = ngan._C, ngan.ops
     prec = C.conv3x3_algorithm(B, H, W, K, N, res, 0)
     if prec != 4:
-        assert (K, N) != (16, 16) and (res != 0 or W % 32), "a Winograd-eligible shape fell back to the direct form"
-        pytest.skip("the 32-channel Winograd kernel takes plain input on whole 32-pixel tiles")
+        assert (K, N) != (16, 16) and W % 32, "a Winograd-eligible shape fell back to the direct form"
+        pytest.skip("the 32-channel Winograd kernels need whole 32-pixel tiles along x")
     torch.manual_seed(B + H + W + epi + om + K + 3 * N)
     hin, win = (H // 2, W // 2) if res == 2 else (H, W)
     x = torch.randn(B, hin, win, K)
