@@ -22,6 +22,9 @@ namespace {
 #ifndef NGAN_TILE_PRE
 #define NGAN_TILE_PRE 1
 #endif
+#ifndef NGAN_TILE_PRE_WINO
+#define NGAN_TILE_PRE_WINO 1
+#endif
 
 template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
 __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_tile_kernel(ConvArgs a, int n_tiles) {
@@ -193,7 +196,9 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
         // PixelNorm-backward operands (same shape as the output): requested before the MFMAs where registers allow, else before the
         // first store of the epilogue (a load issued behind a store can only be awaited by draining that store)
         constexpr bool PNB = EPI == EPI_PN_BWD && OUTMODE == 0;
-        constexpr bool PRE = PNB && MTW * KG > 1 && NGAN_TILE_PRE;
+        // (the 16 -> 16 direct / split-bf16 instances run 3 - 4 workgroups per CU and have no registers for it; the Winograd instance
+        // has 2 per CU and ~170 of 256 registers in use)
+        constexpr bool PRE = PNB && (MTW * KG > 1 || (WINO && NGAN_TILE_PRE_WINO)) && NGAN_TILE_PRE;
         float4 yy[PNB ? PGW : 1][MTW];
         float rr[PNB ? PGW : 1];
         auto load_pn_operands = [&]() {

@@ -27,7 +27,16 @@ struct WgradArgs {
 // MI355X_MICROARCH.md).  Tile order, per-block slabs and the fixed-order reduction are those of wgrad_kernel: bit-reproducible.
 // NW waves: a 16 x 16 (cout, cin) sub-slice per wave group, the tile's rows split over the groups' waves.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }      // smallest m >= n with m = 4 (mod 64)
+#ifndef NGAN_WGRAD_PAD_ODD
+#define NGAN_WGRAD_PAD_ODD 1
+#endif
+#ifndef NGAN_WGRAD_W22
+#define NGAN_WGRAD_W22 8
+#endif
+// plane pitch: the smallest multiple of 4 >= n whose quarter is odd -- the 16 channel lanes of a ds_read_b128 then start at 16
+// distinct multiples of 4 dwords (mod 64): conflict-free.  (Round 2 used "= 4 (mod 64)", one such pitch; for the 10 x 36 halo plane
+// it is 388 dwords against 364 here, and 3 KB less per 32-channel tile is what lets TWO 32 x 32-slice workgroups share a CU.)
+constexpr int pad_plane(int n) { return NGAN_WGRAD_PAD_ODD ? ((n + 3) / 4 * 4 + (((n + 3) / 4) % 2 == 0 ? 4 : 0)) : n + ((4 - n % 64) + 64) % 64; }
 
 // WINO = 1 (16 x 16 slices, 8 x 32 tiles): the contraction in Winograd form, dW = G^T [ sum over 2x2 output tiles of (A dY A^T) . (B^T d B) ] G
 // -- the backward-filter counterpart of conv3x3_tile_kernel's F(2x2, 3x3).  A wave takes one row of 16 tiles; an MFMA contracts over
@@ -37,7 +46,7 @@ constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }      // 
 // The G^T . G back-transform is linear, so every workgroup applies it to its own partial sum before writing the slab: slab
 // format, slab reduction and bit-reproducibility are those of the direct form.
 template <int COT, int CIT, int RES, int TW, int NW, int XF, int WINO = 0>
-__global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
+__global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 || NW == 4 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
     static_assert(!WINO || TW == 32, "Winograd weight gradient: 8 x 32 tiles (a wave takes whole rows of 16 tiles)");
     constexpr int NT = NW * 64;
     constexpr int TH = 256 / TW, HALO_H = TH + 2, NBLK = TW / 16;
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgradPlan { int co_s, ci_s, nslices, n_ci_slices, tiles_x, tiles_y, n_tiles, nwx, tw; };
-constexpr int wgrad_f32_waves(int cot, int cit) { return cot * cit == 4 ? 8 : 4; }    // a 32 x 32 slice: two waves per 16 x 16 sub-slice
+constexpr int wgrad_f32_waves(int cot, int cit) { return cot * cit == 4 ? NGAN_WGRAD_W22 : 4; }    // a 32 x 32 slice: one wave (round 2: two) per 16 x 16 sub-slice
 
 WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout, int precision = 1) {
     WgradPlan p;
@@ -645,7 +654,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout, int precision = 1) 
     // about two resident workgroups per CU: few slabs to reduce afterwards (256 / 768 measured slower).  The fp32 kernel's 32 x 32
     // slices are 8-wave workgroups with 83 KB of LDS, one per CU: 256 of them (fp32 32 -> 32 at 128x128: 100 vs 106 us, 64 -> 64 at
     // 32x32: 33 vs 39 us)
-    const int total = forced > 0 ? forced : ((precision == 0 && p.co_s == 32 && p.ci_s == 32) ? 256 : 512);
+    const int total = forced > 0 ? forced : ((precision == 0 && p.co_s == 32 && p.ci_s == 32 && NGAN_WGRAD_W22 == 8) ? 256 : 512);
     int cap = total / p.nslices;
     if (cap < 1) cap = 1;
     p.nwx = p.n_tiles < cap ? p.n_tiles : cap;

@@ -31,12 +31,16 @@ w = torch.randn(a.N, a.K, 3, 3, device=dev)
 flops = 2.0 * 9 * a.K * a.N * a.B * a.H * a.W
 if a.op == "fwd":
     prec = C.conv3x3_algorithm(a.B, a.H, a.W, a.K, a.N, a.res, a.prec)
-    packed = ops._packed(w, 0, 0.1, prec)
+    packed = ops._packed(w, 1 if a.epi == 2 else 0, 0.1, prec)
     oh, ow = (2 * a.H, 2 * a.W) if a.out else (a.H, a.W)
     y = torch.empty(a.B, oh, ow, a.N, device=dev)
     rn = torch.empty(a.B, a.H, a.W, device=dev)
+    ay = torch.randn(a.B, oh, ow, a.N, device=dev) if a.epi == 2 else (torch.randn(a.N, device=dev) if a.epi == 3 else None)
+    arn = (torch.rand(a.B, oh, ow, device=dev) + 0.5) if a.epi == 2 else None
+    aout = torch.empty(a.B, a.H, a.W, device=dev) if a.epi == 3 else None
     def run():
-        C.call("ngan_conv3x3_fwd", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.res, a.epi, a.out, 0.2, 1e-8, prec, C.CONV_SKIP_BORDER if prec == 3 else 0)
+        C.call("ngan_conv3x3_fwd_ex", x, packed, None, y, rn if a.epi in (1, 3) else None, ay, arn, aout, a.B, a.H, a.W, a.K, a.N, a.res, a.epi, a.out,
+               0.2, 1e-8, prec, C.CONV_SKIP_BORDER if prec == 3 else 0)
         if prec == 3:      # folded bilinear: the border ring is its own launch in the Python layer's split mode (include/ngan.h)
             C.call("ngan_conv3x3_up2_border", x, packed, None, y, rn if a.epi else None, a.B, a.H, a.W, a.K, a.N, a.epi, 0.2, 1e-8)
 else:
