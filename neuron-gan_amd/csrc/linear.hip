@@ -276,7 +276,11 @@ extern "C" int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* 
                  B, K, S, C);
     NGAN_REQUIRE(K % 4 == 0, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: K=%d must be a multiple of 4", K);
     const size_t lds = (size_t)(BCH * (K + 4) + BCH * (C + 4) + BCH) * sizeof(float);
-    NGAN_REQUIRE(lds <= 64 * 1024, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: K=%d C=%d need %zu B of LDS", K, C, lds);
+    NGAN_REQUIRE(lds <= 160 * 1024, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: K=%d C=%d need %zu B of LDS", K, C, lds);
+    if (lds > 64 * 1024) {      // wide stems (the 1024-channel presets): more than the default dynamic-LDS limit of a launch
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        NGAN_REQUIRE(e == hipSuccess, (int)e, "linear_lrelu_pn_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(linear_fwd_kernel, dim3(S, ngan::ceil_div(B, BCH)), dim3(256), lds, (hipStream_t)stream, z, Wt, y, rnorm,
                        B, K, S, C, scale, slope, eps);
     return ngan::launch_status("ngan_linear_lrelu_pn_fwd");

@@ -36,6 +36,18 @@ int reduce_partials(const float* partials, int nparts, int M, float* out, float 
 int reduce_partials_split(const float* partials, int nparts, int M, long stride, float* out, int M1, float* out2, float scale,
                           hipStream_t s);
 
+// wide.hip: the same operators for channel counts outside the lane-group kernels' range (C % 4 == 0, any size)
+int wide_pn_fwd(const float* c, const float* bias, float* y, float* rn, long npix, int C, float slope, float eps, hipStream_t s);
+int wide_pn_bwd(const float* gy, const float* gy2, const float* gr, const float* y, const float* rn, float* gc, long npix, int C, float slope, hipStream_t s);
+int wide_pn_bwdbwd(const float* h, const float* gy, const float* y, const float* rn, float* ggy, float* gy_out, float* gr_out, long npix, int C,
+                   float slope, hipStream_t s);
+int wide_channel_sum(const float* g, float* out, long npix, int C, float scale, hipStream_t s);
+int wide_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, hipStream_t s);
+int wide_to_image_bwd(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw, long npix, int C, int Ncol,
+                      const float* rn, float slope, hipStream_t s);
+int wide_from_image_dx(const float* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool, hipStream_t s);
+int wide_from_image_dw(const float* x, const float* g, float* gw, float* gb, int B, int H, int W, int Ncol, int C, int pool, hipStream_t s);
+
 }  // namespace ngan
 
 // ---- device helpers ---------------------------------------------------------------------------------------

@@ -113,6 +113,7 @@ bool lpp_ok(int C) {
 extern "C" int ngan_lrelu_pixelnorm_fwd(const float* c, const float* bias, float* y, float* rnorm, long npix, int C,
                                         float slope, float eps, void* stream) {
     NGAN_REQUIRE(c && y && rnorm, NGAN_ERR_ARG, "lrelu_pixelnorm_fwd: null pointer");
+    if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C)) return ngan::wide_pn_fwd(c, bias, y, rnorm, npix, C, slope, eps, (hipStream_t)stream);
     NGAN_REQUIRE(npix > 0 && lpp_ok(C), NGAN_ERR_SHAPE, "lrelu_pixelnorm_fwd: npix=%ld C=%d unsupported", npix, C);
     PN_DISPATCH(pn_fwd_kernel, c, bias, y, rnorm, npix, C, slope, eps);
     return ngan::launch_status("ngan_lrelu_pixelnorm_fwd");
@@ -121,6 +122,7 @@ extern "C" int ngan_lrelu_pixelnorm_fwd(const float* c, const float* bias, float
 extern "C" int ngan_lrelu_pixelnorm_bwd2(const float* gy, const float* gy2, const float* gr, const float* y, const float* rnorm,
                                          float* gc, long npix, int C, float slope, void* stream) {
     NGAN_REQUIRE(gy && y && rnorm && gc, NGAN_ERR_ARG, "lrelu_pixelnorm_bwd: null pointer");
+    if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C)) return ngan::wide_pn_bwd(gy, gy2, gr, y, rnorm, gc, npix, C, slope, (hipStream_t)stream);
     NGAN_REQUIRE(npix > 0 && lpp_ok(C), NGAN_ERR_SHAPE, "lrelu_pixelnorm_bwd: npix=%ld C=%d unsupported", npix, C);
     PN_DISPATCH(pn_bwd_kernel, gy, gr, y, rnorm, gc, npix, C, slope, gy2);
     return ngan::launch_status("ngan_lrelu_pixelnorm_bwd");
@@ -135,6 +137,7 @@ extern "C" int ngan_lrelu_pixelnorm_bwdbwd(const float* h, const float* gy, cons
                                            float* ggy, float* gy_out, float* gr_out, long npix, int C, float slope,
                                            void* stream) {
     NGAN_REQUIRE(h && gy && y && rnorm && ggy && gy_out && gr_out, NGAN_ERR_ARG, "lrelu_pixelnorm_bwdbwd: null pointer");
+    if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C)) return ngan::wide_pn_bwdbwd(h, gy, y, rnorm, ggy, gy_out, gr_out, npix, C, slope, (hipStream_t)stream);
     NGAN_REQUIRE(npix > 0 && lpp_ok(C), NGAN_ERR_SHAPE, "lrelu_pixelnorm_bwdbwd: npix=%ld C=%d unsupported", npix, C);
     PN_DISPATCH(pn_bwdbwd_kernel, h, gy, y, rnorm, ggy, gy_out, gr_out, npix, C, slope);
     return ngan::launch_status("ngan_lrelu_pixelnorm_bwdbwd");

@@ -646,6 +646,7 @@ extern "C" int ngan_gp_coef(const float* norms, int B, float lambda, const float
 
 extern "C" int ngan_channel_sum(const float* g, float* out, float* workspace, long npix, int C, float scale, void* stream) {
     NGAN_REQUIRE(g && out && workspace, NGAN_ERR_ARG, "channel_sum: null pointer");
+    if (npix > 0 && C > 0 && !pow2_quads(C)) return ngan::wide_channel_sum(g, out, npix, C, scale, (hipStream_t)stream);     // wide.hip
     NGAN_REQUIRE(npix > 0 && pow2_quads(C), NGAN_ERR_SHAPE, "channel_sum: npix=%ld C=%d unsupported", npix, C);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = stream_blocks(npix, C / 4);
@@ -674,6 +675,8 @@ extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* 
 extern "C" int ngan_from_image_dx(const float* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool,
                                   void* stream) {
     NGAN_REQUIRE(g && w && gx, NGAN_ERR_ARG, "from_image_dx: null pointer");
+    if (B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && !pow2_quads(C))
+        return ngan::wide_from_image_dx(g, w, gx, B, H, W, Ncol, C, pool, (hipStream_t)stream);                                 // wide.hip
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
                  "from_image_dx: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
     NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_dx: B*H*W*C/4 must be below 2^31");
@@ -690,6 +693,8 @@ extern "C" int ngan_from_image_dx(const float* g, const float* w, float* gx, int
 extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
                                   int Ncol, int C, int pool, void* stream) {
     NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "from_image_dw: null pointer");
+    if (B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && !pow2_quads(C))
+        return ngan::wide_from_image_dw(x, g, gw, gb, B, H, W, Ncol, C, pool, (hipStream_t)stream);                             // wide.hip
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
                  "from_image_dw: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
     NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_dw: B*H*W*C/4 must be below 2^31");
@@ -712,6 +717,8 @@ extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, flo
 
 extern "C" int ngan_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, void* stream) {
     NGAN_REQUIRE(x && w && t, NGAN_ERR_ARG, "to_image_fwd: null pointer");
+    if (npix > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0 && !pow2_quads(C))
+        return ngan::wide_to_image_fwd(x, w, t, npix, C, Ncol, (hipStream_t)stream);                                            // wide.hip
     NGAN_REQUIRE(npix > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE, "to_image_fwd: npix=%ld C=%d Ncol=%d unsupported",
                  npix, C, Ncol);
     hipStream_t s = (hipStream_t)stream;
@@ -739,6 +746,8 @@ extern "C" int ngan_to_image_bwd_pnbwd(const float* g, const float* t, const flo
 static int to_image_bwd_impl(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
                              float* workspace, long npix, int C, int Ncol, const float* rn, float slope, void* stream) {
     NGAN_REQUIRE(g && t && x && w && gx && gw && workspace, NGAN_ERR_ARG, "to_image_bwd: null pointer");
+    if (npix > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0 && !pow2_quads(C))
+        return ngan::wide_to_image_bwd(g, t, x, w, gx, gw, npix, C, Ncol, rn, slope, (hipStream_t)stream);                       // wide.hip
     NGAN_REQUIRE(npix > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE, "to_image_bwd: npix=%ld C=%d Ncol=%d unsupported",
                  npix, C, Ncol);
     hipStream_t s = (hipStream_t)stream;
@@ -774,6 +783,10 @@ static int launch_up2_adjoint_strip(const float* g, const float* yprev, const fl
 extern "C" int ngan_up2_adjoint_pnbwd(const float* g, const float* yprev, const float* rnorm, float* o, int B, int h, int w, int C,
                                       float slope, void* stream) {
     NGAN_REQUIRE(g && yprev && rnorm && o, NGAN_ERR_ARG, "ngan_up2_adjoint_pnbwd: null pointer");
+    if (B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0 && !pow2_quads(C)) {      // wide layers: the two operators one after the other (wide.hip)
+        const int st = ngan_up2_adjoint(g, o, B, h, w, C, stream);
+        return st ? st : ngan::wide_pn_bwd(o, nullptr, nullptr, yprev, rnorm, o, (long)B * h * w, C, slope, (hipStream_t)stream);
+    }
     NGAN_REQUIRE(B > 0 && B < 65536 && h > 0 && w > 0 && pow2_quads(C), NGAN_ERR_SHAPE, "ngan_up2_adjoint_pnbwd: bad dims %d %d %d %d", B, h, w, C);
     return launch_up2_adjoint_strip(g, yprev, rnorm, o, B, h, w, C, slope, (hipStream_t)stream);
 }

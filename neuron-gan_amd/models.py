@@ -326,8 +326,8 @@ def _conv_any_width(x, m, res, slope):
     double-backward, so all gradient orders are exact; it is an unfused compatibility path (no PixelNorm hand-off, no ToImage /
     first-block fusion), not a fast one."""
     co, ci = m.weight.shape[0], m.weight.shape[1]
-    if co % 4 or ((co // 4) & (co // 4 - 1)) or co > 256:
-        raise NotImplementedError(f'PixelNorm kernels take 4, 8, 16, ... 256 channels, got {co}')
+    if co % 4:
+        raise NotImplementedError(f'the channels-last kernels take channel counts that are multiples of 4, got {co}')
     cip, cop = -(-ci // 16) * 16, -(-co // 16) * 16
     w = torch.nn.functional.pad(m.weight, (0, 0, 0, 0, 0, cip - ci, 0, cop - co))
     b = torch.nn.functional.pad(m.bias, (0, cop - co)) if m.bias is not None else None

@@ -183,7 +183,10 @@ def test_full_width_pins(ngan, name, conv_precision):
                                                        (1, 16, 0.5, ([32, 8], [8, 32])), (1, 32, 1.0, ([16, 8, 8], [8, 8, 16])),
                                                        # wide blocks shaped like the presets 0006-0008 (configs/config.py:90-98): more
                                                        # than 128 channels per conv run as output-channel chunks (ops._n_chunks)
-                                                       (1, 32, 1.0, ([256, 128, 64], [64, 128, 256])), (1, 16, 0.5, ([256, 128], [128, 256]))])
+                                                       (1, 32, 1.0, ([256, 128, 64], [64, 128, 256])), (1, 16, 0.5, ([256, 128], [128, 256])),
+                                                       # 512 / 1024 channels (presets 0004-0008) and widths whose quarter is not a power of two:
+                                                       # per-pixel operators through csrc/wide.hip
+                                                       (1, 16, 1.0, ([1024, 512], [256, 512])), (1, 16, 0.5, ([96, 48], [48, 96]))])
 def test_losses_and_gradients_match_oracle_on_the_fly(ngan, n_colors, res, alpha, widths, conv_precision):
     """Configurations the committed fixtures do not hold (RGB images: the reference's N_colors constructor argument; a 32x32 stable
     stage of a three-block net): one critic loss + gradient penalty + generator loss against the CPU oracle evaluated here on the
