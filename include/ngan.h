@@ -100,6 +100,11 @@ int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, flo
 int ngan_conv3x3_up2_border(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                             int B, int H, int W, int K, int N, int epilogue, float slope, float eps, void* stream);
 int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision);
+/* Pooled side output of epilogue 1: where this returns 1 (the Winograd kernels, precision code 4, on whole 32-pixel tiles and even
+ * H), ngan_conv3x3_fwd_ex with epilogue 1 and aux_out != NULL also writes aux_out (B, H/2, W/2, N) = the 2x2 average of y -- the
+ * input of the next block's AvgPool2d(2) + conv (models.py:252-254) -- with the association of ngan_pool2_fwd, i.e. the same
+ * bits a separate pooling pass over y would give.  Elsewhere aux_out must be NULL for epilogue 1. */
+int ngan_conv3x3_pooled_output(int B, int H, int W, int K, int N, int resample, int precision);
 int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                         const float* aux_in, const float* aux_rn, float* aux_out,
                         int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,

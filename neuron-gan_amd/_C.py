@@ -74,6 +74,7 @@ NON_STATUS = {
     "ngan_conv3x3_kernel_name": ([_I, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I], _I),
     "ngan_conv3x3_algorithm": ([_I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_epilogue_fused": ([_I, _I, _I, _I, _I, _I, _I, _I, _I], _I),
+    "ngan_conv3x3_pooled_output": ([_I, _I, _I, _I, _I, _I, _I], _I),
     "ngan_conv3x3_packed_floats": ([_I, _I, _I], _L),
     "ngan_conv3x3_pack_elements": ([_I, _I, _I, _I], _L),
     "ngan_conv3x3_wgrad_plan": ([_I, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int)], _I),
@@ -177,6 +178,10 @@ def conv3x3_algorithm(B, H, W, K, N, resample, precision) -> int:
 
 def conv3x3_epilogue_fused(B, H, W, K, N, resample, epilogue, out_mode, precision) -> bool:
     return bool(lib().ngan_conv3x3_epilogue_fused(B, H, W, K, N, resample, epilogue, out_mode, precision))
+
+
+def conv3x3_pooled_output(B, H, W, K, N, resample, precision) -> bool:
+    return bool(lib().ngan_conv3x3_pooled_output(B, H, W, K, N, resample, precision))
 
 
 def conv3x3_packed_floats(cout, cin, precision) -> int:

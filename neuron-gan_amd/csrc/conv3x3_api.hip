@@ -26,6 +26,14 @@ extern "C" int ngan_conv3x3_algorithm(int B, int H, int W, int K, int N, int res
 // exact-fp32 layers with 32..128 channels on small images run in the fp32 variant of the mid kernel
 static bool mid_f32_enabled() { return NGAN_DIAG_FLAG("NGAN_MID_F32", true); }
 
+// epilogue 1 can also write y averaged over 2x2 blocks (aux_out of ngan_conv3x3_fwd_ex): the Winograd kernels on whole tiles, whose
+// lanes own exactly one pooling window each
+extern "C" int ngan_conv3x3_pooled_output(int B, int H, int W, int K, int N, int resample, int precision) {
+    if (precision != 4 || B <= 0 || H <= 0 || W <= 0 || (H & 1) || W % 32) return 0;
+    if (resample == NGAN_RESAMPLE_UP2 && !NGAN_DIAG_FLAG("NGAN_WINOGRAD_UP2", true) && K == 16 && N == 16) return 0;   // (conv3x3_persist_kernel)
+    return ngan_conv3x3_algorithm(B, H, W, K, N, resample, 0) == 4 ? 1 : 0;
+}
+
 extern "C" int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision) {
     if (epilogue == EPI_NONE || epilogue == EPI_LRELU_PN) return 1;
     if (B <= 0 || H <= 0 || W <= 0) return 0;
@@ -54,6 +62,8 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
     NGAN_REQUIRE(out_mode == 0 || (out_mode == 1 && (epilogue == EPI_NONE || epilogue == EPI_PN_BWD) && resample == 0), NGAN_ERR_ARG,
                  "conv3x3_fwd: out_mode %d needs epilogue 0 or 2 and resample 0", out_mode);
     NGAN_REQUIRE(epilogue != EPI_LRELU_PN || rnorm, NGAN_ERR_ARG, "conv3x3_fwd: epilogue 1 needs rnorm");
+    NGAN_REQUIRE(epilogue != EPI_LRELU_PN || !aux_out || ngan_conv3x3_pooled_output(B, H, W, K, N, resample, precision), NGAN_ERR_ARG,
+                 "conv3x3_fwd: epilogue 1 writes a pooled side output (aux_out) only where ngan_conv3x3_pooled_output(...) returns 1");
     NGAN_REQUIRE(epilogue != EPI_PN_BWD || (aux_in && aux_rn && resample == 0 && !bias), NGAN_ERR_ARG,
                  "conv3x3_fwd: epilogue 2 needs aux_in / aux_rn, no resampling and no bias");
     NGAN_REQUIRE(epilogue != EPI_TO_IMAGE || (aux_in && aux_out && (!y || rnorm) &&

@@ -321,6 +321,9 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
         // last lanes of a pixel group (tools/dbg_epi2.py; without the prefetch the kernel is bit-identical to conv3x3_persist_kernel)
         if (PNB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float timg = 0.f;
+        // pooled side output (Winograd form, epilogue 1, a.aout given): the lane's four pixel groups ARE one 2x2 pooling window
+        constexpr bool POOL_OUT = WINO && EPI == EPI_LRELU_PN && OUTMODE == 0;
+        f32x2 plo[POOL_OUT ? 2 : 1][MTW], phi[POOL_OUT ? 2 : 1][MTW];
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg) {
             f32x2 lo[MTW], hi[MTW];                 // channels (4q, 4q+1) and (4q+2, 4q+3) of each 16-channel tile
@@ -349,6 +352,13 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
                 // the norm: one lane per pixel stores, the others' offset is out of range (a branch here would also cut the epilogue
                 // into basic blocks and keep the four pixel groups' reduction chains from being scheduled side by side)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m * inv), rn_rsrc, q == 0 ? (e_voff[pg] >> NSHIFT) + p_soff : OOB, 0, 0);
+            }
+            if (POOL_OUT) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {         // (a + b) + (c + d), the association of ngan_pool2_fwd
+                    plo[POOL_OUT ? pg >> 1 : 0][mt] = (pg & 1) ? plo[POOL_OUT ? pg >> 1 : 0][mt] + lo[mt] : lo[mt];
+                    phi[POOL_OUT ? pg >> 1 : 0][mt] = (pg & 1) ? phi[POOL_OUT ? pg >> 1 : 0][mt] + hi[mt] : hi[mt];
+                }
             }
             if (EPI == EPI_TO_IMAGE) {
                 f32x2 d2 = {0.f, 0.f};
@@ -428,6 +438,19 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4[mt]), y_rsrc,
                                                                e_voff[pg] + ((sub >> 1) ? row1 : y_soff) + mt * 64 + (sub & 1) * (N * 4), 0, 0);
                 }
+            }
+        }
+        if (POOL_OUT && a.aout) {
+            // y averaged over the lane's 2x2 block -> (B, H/2, W/2, N): what the next block's avg-pooled conv would otherwise make with
+            // a pass of its own (ops._pool_first); same association as ngan_pool2_fwd, so the bits are the same
+            const int hw2 = (a.H >> 1) * (a.W >> 1);
+            const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.aout + (long)b * hw2 * N, 0, (unsigned)(hw2 * N) * 4u, 0x00020000);
+            const unsigned poff = (unsigned)(((((y0 >> 1) + wave) * (a.W >> 1) + (x0 >> 1) + p) * N + q * 4) * 4);
+            const f32x2 quarter = {0.25f, 0.25f};
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const f32x2 l = (plo[0][mt] + plo[POOL_OUT ? 1 : 0][mt]) * quarter, h = (phi[0][mt] + phi[POOL_OUT ? 1 : 0][mt]) * quarter;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(l.x, l.y, h.x, h.y)), p_rsrc, poff + mt * 64, 0, 0);
             }
         }
         if (EPI == EPI_TO_IMAGE) {

@@ -385,6 +385,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
                     dd[pg] = sum_rows4(d2.x + d2.y);
                 }
             }
+            if (EPI == EPI_LRELU_PN && a.aout) {
+                // pooled side output: y averaged over the lane's 2x2 block -> (B, H/2, W/2, N), what the next block's avg-pooled conv
+                // would otherwise make with a pass of its own (ops._pool_first); (a + b) + (c + d) as in ngan_pool2_fwd: same bits
+                const int hw2 = (a.H >> 1) * (a.W >> 1);
+                const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.aout + (long)b * hw2 * N, 0, (unsigned)(hw2 * N) * 4u, 0x00020000);
+                const unsigned poff = (unsigned)(((((y0 >> 1) + tr) * (a.W >> 1) + (x0 >> 1) + p) * N + cb + q * 4) * 4);
+                const f32x2 quarter = {0.25f, 0.25f};
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const f32x2 l = ((lo[0][mt] + lo[1][mt]) + (lo[2][mt] + lo[3][mt])) * quarter, h = ((hi[0][mt] + hi[1][mt]) + (hi[2][mt] + hi[3][mt])) * quarter;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(l.x, l.y, h.x, h.y)), p_rsrc, poff + mt * 64, 0, 0);
+                }
+            }
             if (EPI == EPI_TO_IMAGE) {
                 exchange(dd, PGW, 1);
 #pragma unroll

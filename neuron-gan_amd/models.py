@@ -363,7 +363,13 @@ def _exec(steps, x, link=None, to_image=None):
                                                  torch.is_grad_enabled())
                 return t, None
             out_link = ops.PNLink() if linking else None
-            if link is not None or out_link is not None:
+            # the next step is an avg-pooled conv: ask this conv's kernel for the pooled copy of its output (ops._run_conv)
+            nxt = steps[idx + 1] if idx < last else None
+            pool_out = (nxt is not None and nxt[0] in ('conv_lrelu_pn', 'conv') and len(nxt) > 2 and nxt[2] == ops.RES_POOL2
+                        and not _odd_width(nxt[1]))
+            if pool_out:
+                x, _ = ops.ConvLReLUPN.apply(x, m.weight, m.bias, res, m.scale_value, slope, link, out_link, True)
+            elif link is not None or out_link is not None:
                 x, _ = ops.ConvLReLUPN.apply(x, m.weight, m.bias, res, m.scale_value, slope, link, out_link)
             else:
                 x, _ = ops.ConvLReLUPN.apply(x, m.weight, m.bias, res, m.scale_value, slope)

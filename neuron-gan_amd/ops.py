@@ -245,6 +245,7 @@ def _pool_first(resample):
 
 
 _pool_first_allowed = os.environ.get("NGAN_POOL_FIRST", "1") != "0"     # A/B switch for measurements and tests
+_pool_out_allowed = os.environ.get("NGAN_POOL_OUT", "1") != "0"         # A/B switch: pooled side output of the producing conv
 
 
 def _pooled(x):
@@ -269,11 +270,13 @@ def _n_chunks(n):
     return out
 
 
-def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=None):
+def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=None, pool_out=False):
     """y (and rnorm) = epilogue(conv3x3(resample(x), scale*W) + bias); keep_pooled: a list that receives the pooled input copy
-    when one was made (`_pool_first`)"""
+    when one was made (`_pool_first`); pool_out: the consumer of y is an avg-pooled conv -- where the kernel can, it also writes
+    the 2x2 average of y, which travels with y as `y._ngan_pooled` (same bits as the pooling pass it replaces)"""
     if _pool_first(resample):
-        x = _pooled(x)
+        side = getattr(x, "_ngan_pooled", None)
+        x = side if side is not None and side.shape[1] * 2 == x.shape[1] else _pooled(x)
         resample = RES_NONE
         if keep_pooled is not None:
             keep_pooled.append(x)
@@ -295,6 +298,12 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=Non
         return y, rn
     prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
     packed = _packed(weight, 0, scale, prec)
+    if pool_out and epilogue == EPI_LRELU_PN and _pool_out_allowed and _C.conv3x3_pooled_output(b, h, w, cin, cout, resample, prec):
+        yp = torch.empty((b, h // 2, w // 2, cout), device=x.device, dtype=torch.float32)
+        _C.call("ngan_conv3x3_fwd_ex", x, packed, bias, y, rn, None, None, yp, b, h, w, cin, cout, resample, epilogue, 0, float(slope),
+                PIXELNORM_EPS, prec, 0)
+        y._ngan_pooled = yp
+        return y, rn
     _C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0, float(slope), PIXELNORM_EPS, prec,
             _C.CONV_SKIP_BORDER if prec == 3 else 0)
     if prec == 3:      # bilinear x2 folded into the weights: the border ring is a launch of its own (NGAN_CONV_SKIP_BORDER, include/ngan.h)
@@ -469,16 +478,16 @@ class ConvLReLUPN(Function):
     Optional `in_link` / `out_link` (PNLink): see `first_order_only`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resample, scale, slope, in_link=None, out_link=None):
+    def forward(ctx, x, weight, bias, resample, scale, slope, in_link=None, out_link=None, pool_out=False):
         ctx.set_materialize_grads(False)
         x = _c(x)
         kept = []
-        y, rn = _run_conv(x, weight, bias, resample, scale, 1, slope, keep_pooled=kept)
+        y, rn = _run_conv(x, weight, bias, resample, scale, 1, slope, keep_pooled=kept, pool_out=pool_out)
         ctx.save_for_backward(x, weight, y, rn)
         ctx.pooled = kept[0] if kept else None        # (an intermediate of this node, not an input: held outside saved_tensors)
         ctx.has_bias = bias is not None
         ctx.cfg = (resample, scale, slope)
-        ctx.n_in = 6 + (in_link is not None or out_link is not None) * 2
+        ctx.n_in = 6 + (3 if pool_out else (in_link is not None or out_link is not None) * 2)
         if in_link is not None and (in_link.y.data_ptr() != x.data_ptr() or in_link.y.shape != x.shape):
             raise RuntimeError("PixelNorm hand-off: the conv's input is not the linked producer's output")
         ctx.in_link, ctx.out_link = in_link, out_link
