@@ -27,16 +27,13 @@ struct WgradArgs {
 // MI355X_MICROARCH.md).  Tile order, per-block slabs and the fixed-order reduction are those of wgrad_kernel: bit-reproducible.
 // NW waves: a 16 x 16 (cout, cin) sub-slice per wave group, the tile's rows split over the groups' waves.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef NGAN_WGRAD_PAD_ODD
-#define NGAN_WGRAD_PAD_ODD 1
-#endif
 #ifndef NGAN_WGRAD_W22
 #define NGAN_WGRAD_W22 8
 #endif
-// plane pitch: the smallest multiple of 4 >= n whose quarter is odd -- the 16 channel lanes of a ds_read_b128 then start at 16
-// distinct multiples of 4 dwords (mod 64): conflict-free.  (Round 2 used "= 4 (mod 64)", one such pitch; for the 10 x 36 halo plane
-// it is 388 dwords against 364 here, and 3 KB less per 32-channel tile is what lets TWO 32 x 32-slice workgroups share a CU.)
-constexpr int pad_plane(int n) { return NGAN_WGRAD_PAD_ODD ? ((n + 3) / 4 * 4 + (((n + 3) / 4) % 2 == 0 ? 4 : 0)) : n + ((4 - n % 64) + 64) % 64; }
+// smallest m >= n with m = 4 (mod 64).  (Round 3 tried the smaller "any pitch whose quarter is odd" -- 364 instead of 388 dwords for
+// the 10 x 36 halo plane: the Winograd form's reads add 8 q to the lane address, and with a pitch of 44 (mod 64) six of the sixteen
+// lanes of a ds_read_b128 group collide instead of two: the 16 -> 16 kernel went from 51 to 106 us per launch.  Reverted.)
+constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }
 
 // WINO = 1 (16 x 16 slices, 8 x 32 tiles): the contraction in Winograd form, dW = G^T [ sum over 2x2 output tiles of (A dY A^T) . (B^T d B) ] G
 // -- the backward-filter counterpart of conv3x3_tile_kernel's F(2x2, 3x3).  A wave takes one row of 16 tiles; an MFMA contracts over
