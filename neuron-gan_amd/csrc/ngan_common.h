@@ -82,13 +82,16 @@ __device__ __forceinline__ float vmax1(float a, float b) {
 // (v_permlane16_swap: odd rows of the first register <-> even rows of the second; v_permlane32_swap: upper half <-> lower half),
 // which are VALU instructions: the shuffles compile to ds_bpermute_b32, an LDS round trip with a full `s_waitcnt lgkmcnt(0)` each,
 // i.e. two serial LDS latencies per pixel group in every PixelNorm epilogue.  (Inline asm: the builtin's second result came back
-// aliased to the first in this compiler.)  s_nop 1: the swap reads its operands as a VALU-written pair.
+// aliased to the first in this compiler.)  s_nop 1 in front: the swap reads its operands as a VALU-written pair.  s_nop 1 behind:
+// the hazard recogniser does not look inside an asm statement, so the wait states between the swap and whatever consumes its
+// result are spelled out here instead of being left to the schedule (the compiler happened to put one s_nop 0 there; after an
+// inlining change it might not -- round-2 advisor note; the same blindness lost MFMA wait states once).
 __device__ __forceinline__ float sum_rows4(float v) {
     float w = v;
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v), "+v"(w));
     v += w;
     w = v;
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v), "+v"(w));
     return v + w;
 }
 

@@ -1,4 +1,10 @@
-"""Root-cause probe for the abort on record in gpurun_out/fd2.log (round 1):
+"""RECORD ONLY -- do not run on the GPU pool again.  Three of its four cases end in the process-group watchdog's std::terminate
+by design (an RCCL group alive, an active capture); the cause they established is fixed by construction
+(PGGANTrainer._on_comm_stream + thread_local capture mode), the surviving case is covered by
+tests/test_gpu_dist.py::test_segmented_capture_with_a_live_rccl_group_matches_eager, and the output of the one run that was needed is
+profiles/r02_capture_event_probe.txt.
+
+Root-cause probe for the abort on record in gpurun_out/fd2.log (round 1):
 
     Process group watchdog thread terminated with exception: HIP error: operation not permitted on an event last recorded in a
     capturing stream (hipErrorCapturedEvent)   raised from WorkNCCL::finishedGPUExecutionInternal -> ncclEndEvent_->query()
@@ -60,6 +66,9 @@ def child(where, mode):
 
 
 if __name__ == "__main__":
+    import os as _os, sys as _sys
+    if _os.environ.get("NGAN_ALLOW_ABORTING_PROBE") != "1":
+        _sys.exit("record-only tool (provokes process aborts on the GPU box); see the docstring")
     if len(sys.argv) == 3:
         child(sys.argv[1], sys.argv[2])
         sys.exit(0)
