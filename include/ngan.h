@@ -57,12 +57,15 @@ int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int Cout, int 
  *     holds four 3x3 weight sets over the LOW-resolution input, one per output parity (py, px),
  *     W_eff[dr][dc] = sum_{ky,kx} W[ky][kx] * E[py][ky][dr] * E[px][kx][dc]  (E: the .25/.75 blend rows of upsample_bilinear2d,
  *     align_corners = False), followed by the scaled fp32 weights for the one-pixel border ring (mode 0 only);
- *   4 exact fp32 by Winograd F(2x2, 3x3) (answered for a REQUESTED precision 0 on the 16 -> 16 layers of large images, plain or
- *     bilinear input): `packed` holds the 16 transformed weight sets G g G^T (16 * Cin * Cout floats), the kernel transforms 4x4
- *     input patches (B^T d B) and 2x2 output tiles (A^T M A) per lane and spends 64 instead of 144 v_mfma_f32_16x16x4_f32 per
- *     64 pixels.  fp32 arithmetic throughout; its error against an fp64 convolution is no larger than the direct form's
- *     (tools/wino_check.py: relative L2 1.5e-7 against 2.6e-7).  NGAN_WINOGRAD=0 in the environment answers 0 instead.
- * (The function keeps its round-1 name; what it returns is the precision code for any requested precision.) */
+ *   4 exact fp32 by Winograd F(2x2, 3x3) (answered for a REQUESTED precision 0 on large images: the 16 -> 16 layers with plain or
+ *     bilinear input, and -- on widths that are multiples of 32 -- every shape with K, N in {16, 32}, plain or bilinear input):
+ *     `packed` holds the 16 transformed weight sets G g G^T (16 * Cin * Cout floats), the kernel transforms 4x4 input patches
+ *     (B^T d B; bilinear input: (B^T E) L (B^T E)^T straight from the 3x3 low-resolution patch) and 2x2 output tiles (A^T M A) per
+ *     lane and spends 16 instead of 36 v_mfma_f32_16x16x4_f32 per 16 pixels and 16 x 16 channel pair.  fp32 arithmetic throughout;
+ *     its error against an fp64 evaluation of the fused operator is below 1e-6 relative L2 (tests/test_gpu_ops.py::
+ *     test_winograd_kernels_against_fp64; the direct form: 2.6e-7 against 1.5e-7 on the same operands).
+ * The answer depends on the shape only: the library reads no environment variable (the measurement switches that select the
+ * direct forms exist in the diagnostic build, `make diag`, only). */
 int ngan_conv3x3_algorithm(int B, int H, int W, int K, int N, int resample, int precision);
 long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision);   /* size of `packed` in floats */
 
@@ -79,7 +82,8 @@ int ngan_conv3x3_pack_many(const void* table, int n_entries, long total_elements
  *   bias     N floats or NULL
  *   epilogue 0: y = conv (+bias)            1: y = PixelNorm(LeakyReLU(conv + bias)), rnorm (B,H,W) = sqrt(mean_c a^2 + eps)
  *   out_mode 0: y is (B,H,W,N)              1: avg-pool adjoint store: y is (B,2H,2W,N), each value * 0.25 to its 2x2 block
- * K = contraction channels, N = output channels (N <= 128 per call). */
+ * K = contraction channels (any multiple of 16), N = output channels: 16, 32, 64 or 128 per call (the Python layer runs wider
+ * layers as output-channel chunks of these sizes, ops._n_chunks). */
 int ngan_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* y, float* rnorm,
                      int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
                      float slope, float eps, int precision, int flags, void* stream);
@@ -123,7 +127,7 @@ int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int r
  * accumulate != 0: gw += ... (adds into an existing gradient buffer).  workspace: ngan_conv3x3_wgrad_workspace_bytes(...) bytes.
  * precision 0 on images wider than 16 pixels contracts in Winograd form, dW = G^T [ sum over 2x2 output tiles (A dY A^T) . (B^T d B) ] G
  * (fp32 arithmetic, 16 position accumulators instead of 9 taps, the back-transform applied to every partial sum before it is written:
- * same slabs, same fixed-order reduction); NGAN_WINOGRAD_WGRAD=0 in the environment selects the direct contraction. */
+ * same slabs, same fixed-order reduction). */
 size_t ngan_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
                        int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate, int precision,
