@@ -30,6 +30,9 @@ struct WgradArgs {
 #ifndef NGAN_WGRAD_W22
 #define NGAN_WGRAD_W22 8
 #endif
+#ifndef NGAN_WGRAD_SMALL
+#define NGAN_WGRAD_SMALL (1 << 30)
+#endif
 // smallest m >= n with m = 4 (mod 64).  (Round 3 tried the smaller "any pitch whose quarter is odd" -- 364 instead of 388 dwords for
 // the 10 x 36 halo plane: the Winograd form's reads add 8 q to the lane address, and with a pitch of 44 (mod 64) six of the sixteen
 // lanes of a ds_read_b128 group collide instead of two: the 16 -> 16 kernel went from 51 to 106 us per launch.  Reverted.)
@@ -48,12 +51,24 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
     constexpr int NT = NW * 64;
     constexpr int TH = 256 / TW, HALO_H = TH + 2, NBLK = TW / 16;
     constexpr int CO_S = COT * 16, CI_S = CIT * 16;
-    constexpr int WO = COT * CIT, WR = NW / WO, RPW = TH / WR;                   // wave groups over sub-slices / over rows
+    constexpr int WO = COT * CIT, WR = NW / WO, RPW = TH / WR;                   // wave groups over sub-slices / over rows (direct form)
     constexpr int XP = TW + 4;                                                   // x row pitch (TW + 2 used), a multiple of 4
     constexpr int PLANE_G = pad_plane(TH * TW), PLANE_X = pad_plane(HALO_H * XP);
     constexpr int G_ELEMS = CO_S * PLANE_G, X_ELEMS = CI_S * PLANE_X;
     constexpr int NACC = WINO ? 16 : 9;
-    constexpr int RED_ELEMS = NW * (WINO ? 8 : 9) * 64 * 4;      // (Winograd: the 16 positions cross the waves in two halves of 8)
+    // Winograd form: a wave owns ONE 16-channel input group and ALL the slice's output groups (COT accumulator sets): the 4x4 input
+    // patch transform B^T d B -- two thirds of the form's VALU work -- is then done once per (tile, input group), not once per
+    // (cout, cin) wave pair as in the direct form's mapping (round 3: 2.75 -> 1.75 VALU instructions per MFMA on 32 x 32 slices).
+    // (where the registers allow: the 8-wave 32 x 32 slices with plain / pooled input; 4-wave workgroups stage twice the tile per
+    // thread and spilled 70 - 160 registers with two accumulator sets, the bilinear instance 56)
+    constexpr bool SHARE = WINO && NW == 8 && RES != NGAN_RESAMPLE_UP2;
+    constexpr int CW = SHARE ? COT : 1;                          // output groups per wave
+    constexpr int WQ = (COT / CW) * CIT;                         // wave groups over (output group sets, input groups)
+    constexpr int WRW = NW / WQ, RPWW = TH / WRW;                // Winograd: row groups, rows per wave
+    static_assert(!WINO || (NW % WQ == 0 && TH % WRW == 0 && RPWW % 2 == 0), "Winograd wave split");
+    // the 16 positions cross the waves in four passes of 4 (virtual wave = (row group, sub-slice)); the back-transform needs 12 per item
+    constexpr int RED_WINO = (WRW * WO * 4 > WO * 12 ? WRW * WO * 4 : WO * 12) * 64 * 4;
+    constexpr int RED_ELEMS = WINO ? RED_WINO : NW * 9 * 64 * 4;
     // bilinear input: the low-resolution source patch of the halo tile is loaded once (fp32, [py][px][CI_S]) and expanded LDS -> LDS,
     // as in wgrad_bf16x3_kernel: 2 global loads per thread instead of 24, and the tap / weight arithmetic is tile-invariant
     constexpr int PH = TH / 2 + 2, PW = TW / 2 + 2, NPP = PH * PW;
@@ -114,9 +129,16 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
         xf_bits = used ? ((side ? 2 : 1) | (r == 0 ? 4 : 0)) : 8;
     }
 
-    f32x4 acc[NACC];
+    f32x4 acc[WINO ? 1 : NACC];                      // direct form: one (cout, cin) sub-slice per wave
+    f32x4 accw[WINO ? CW : 1][16];                   // Winograd form: CW output groups of the slice, one input group
 #pragma unroll
-    for (int t = 0; t < NACC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < (WINO ? 1 : NACC); ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < (WINO ? CW : 1); ++c)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) accw[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wqw = wave % WQ, wrw = wave / WQ;      // Winograd: this wave's (output group set, input group) and row group
+    const int citw = wqw % CIT, cot0w = (wqw / CIT) * CW;
 
     float4 gst[NG], xst[XF ? NXF : (RES == NGAN_RESAMPLE_UP2 ? NXP : NX)];
     constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -239,18 +261,19 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
         const int tn = tile + gridDim.x;
         if (tn < a.n_tiles) issue(tn);   // next tile's loads are in flight during the MFMAs
         if (WINO) {
-            // this wave's tile row: output rows 2 wr, 2 wr + 1 = halo rows 2 wr .. 2 wr + 3.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] is used
+            // this wave's tile rows: output rows row0, row0 + 1 = halo rows row0 .. row0 + 3.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] is used
             // without the minus signs of its last row (one negation per element saved); the back-transform flips the sign of every
             // position with u = 3 xor v = 3 instead.
             // lane (p, q) owns the four consecutive tiles 4 q .. 4 q + 3 of the row (K-step ks contracts tiles 4 q + ks over q): two tiles
-            // at a time are one 16-byte + one 8-byte read per input row and one 16-byte read per gradient row
+            // at a time are one 16-byte + one 8-byte read per input row and one 16-byte read per gradient row and output group
 #pragma unroll
-            for (int tr = 0; tr < RPW / 2; ++tr) {                          // this wave's rows of tiles (RPW output rows)
-            const float* gp = ga - 4 * q + (wr * RPW + 2 * tr) * TW + 8 * q;          // ga = plane p + 4 q: back to the plane, then column 8 q
-            const float* xp = xa - 4 * q + (wr * RPW + 2 * tr) * XP + 8 * q;
+            for (int tr = 0; tr < RPWW / 2; ++tr) {
+            const int row0 = wrw * RPWW + 2 * tr;
+            const float* gp = g_lds + (cot0w * 16 + p) * PLANE_G + row0 * TW + 8 * q;       // + c * 16 * PLANE_G per output group
+            const float* xp = x_lds + (citw * 16 + p) * PLANE_X + row0 * XP + 8 * q;
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
-                float xr[4][6], gr[2][4];
+                float xr[4][6], gr[CW][2][4];
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const float4 lo = ld4(xp + r4 * XP + 4 * kp);
@@ -258,13 +281,15 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
                     xr[r4][0] = lo.x; xr[r4][1] = lo.y; xr[r4][2] = lo.z; xr[r4][3] = lo.w; xr[r4][4] = hi.x; xr[r4][5] = hi.y;
                 }
 #pragma unroll
-                for (int r2 = 0; r2 < 2; ++r2) {
-                    const float4 v = ld4(gp + r2 * TW + 4 * kp);
-                    gr[r2][0] = v.x; gr[r2][1] = v.y; gr[r2][2] = v.z; gr[r2][3] = v.w;
-                }
+                for (int c = 0; c < CW; ++c)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const float4 v = ld4(gp + c * 16 * PLANE_G + r2 * TW + 4 * kp);
+                        gr[c][r2][0] = v.x; gr[c][r2][1] = v.y; gr[c][r2][2] = v.z; gr[c][r2][3] = v.w;
+                    }
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
-                    float t[4][4], V[4][4], sg[4][2], M[4][4];
+                    float t[4][4], V[4][4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float d0 = xr[0][2 * t2 + c], d1 = xr[1][2 * t2 + c], d2 = xr[2][2 * t2 + c], d3 = xr[3][2 * t2 + c];
@@ -273,17 +298,21 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { V[u][0] = t[u][0] - t[u][2]; V[u][1] = t[u][1] + t[u][2]; V[u][2] = t[u][2] - t[u][1]; V[u][3] = t[u][1] - t[u][3]; }
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const float g0 = gr[0][2 * t2 + c], g1 = gr[1][2 * t2 + c];
-                        sg[0][c] = g0; sg[1][c] = g0 + g1; sg[2][c] = g0 - g1; sg[3][c] = g1;
+                    for (int co = 0; co < CW; ++co) {
+                        float sg[4][2], M[4][4];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const float g0 = gr[co][0][2 * t2 + c], g1 = gr[co][1][2 * t2 + c];
+                            sg[0][c] = g0; sg[1][c] = g0 + g1; sg[2][c] = g0 - g1; sg[3][c] = g1;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { M[u][0] = sg[u][0]; M[u][1] = sg[u][0] + sg[u][1]; M[u][2] = sg[u][0] - sg[u][1]; M[u][3] = sg[u][1]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                accw[WINO ? co : 0][u * 4 + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[u][v], V[u][v], accw[WINO ? co : 0][u * 4 + v], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { M[u][0] = sg[u][0]; M[u][1] = sg[u][0] + sg[u][1]; M[u][2] = sg[u][0] - sg[u][1]; M[u][3] = sg[u][1]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            acc[u * 4 + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[u][v], V[u][v], acc[u * 4 + v], 0, 0, 0);
                 }
             }
             }
@@ -323,28 +352,31 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
         __syncthreads();
     }
     if (WINO) {
-        // item (l, u, o): row u of the summed 4x4 position tile of lane l of sub-slice o (its WR waves in fixed order), multiplied by G
-        // from the right:  Z[u][j] = sum_v s_v dU[u][v] G[v][j],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  s = (1, 1, 1, -1) (MFMA section)
+        // item (l, u, o): row u of the summed 4x4 position tile of lane l of sub-slice o = cot * CIT + cit (its WRW row-group waves in fixed
+        // order), multiplied by G from the right:  Z[u][j] = sum_v s_v dU[u][v] G[v][j],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
+        // s = (1, 1, 1, -1) (MFMA section).  The positions cross the waves in four passes, one row u of the position tile each.
         constexpr int ITEMS = WO * 4 * 64, NIT = (ITEMS + NT - 1) / NT;
         float4 du[NIT][4];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half) __syncthreads();
+        for (int pass = 0; pass < 4; ++pass) {
+            if (pass) __syncthreads();
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const f32x4 v = acc[half * 8 + t];
-                red[(wave * 8 + t) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-            }
+            for (int c = 0; c < CW; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 a4 = accw[WINO ? c : 0][pass * 4 + v];
+                    red[((wrw * WO + (cot0w + c) * CIT + citw) * 4 + v) * 64 + lane] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+                }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int item = tid + it * NT, l = item & 63, u = (item >> 6) & 3, o = item >> 8;
-                if (item < ITEMS && (u >> 1) == half) {
+                if (item < ITEMS && u == pass) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        float4 sum = red[((0 * WO + o) * 8 + (u & 1) * 4 + v) * 64 + l];        // wave index = wr * WO + wo
+                        float4 sum = red[((0 * WO + o) * 4 + v) * 64 + l];
 #pragma unroll
-                        for (int w = 1; w < WR; ++w) sum = f4add(sum, red[((w * WO + o) * 8 + (u & 1) * 4 + v) * 64 + l]);
+                        for (int w = 1; w < WRW; ++w) sum = f4add(sum, red[((w * WO + o) * 4 + v) * 64 + l]);
                         du[it][v] = sum;
                     }
                 }
@@ -639,14 +671,19 @@ constexpr int wgrad_f32_waves(int cot, int cit) { return cot * cit == 4 ? NGAN_W
 
 WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout, int precision = 1) {
     WgradPlan p;
-    p.co_s = (Cout % 32 == 0) ? 32 : 16;
-    p.ci_s = (Cin % 32 == 0) ? 32 : 16;
-    p.n_ci_slices = Cin / p.ci_s;
-    p.nslices = (Cout / p.co_s) * p.n_ci_slices;
     p.tw = W <= 16 ? 16 : 32;   // 16x16-pixel tiles for narrow images, 8x32 otherwise
     p.tiles_x = ngan::ceil_div(W, p.tw);
     p.tiles_y = ngan::ceil_div(H, 256 / p.tw);
     p.n_tiles = B * p.tiles_x * p.tiles_y;
+    // fp32 layers with at most 32 channels on either side: 16 x 16 slices -- four times the workgroups of a 32 x 32 slicing, three
+    // resident per CU instead of one 8-wave workgroup.  Measured per tile count (NGAN_WGRAD_SMALL = threshold, round 3): 32 -> 32 at
+    // 64x64, batch 16 / 32: 23.6 -> 18.5 / 29.3 -> 25.6 us; at 128x128, batch 16: 43.6 -> 41.0; batch 32: 71.0 -> 71.4; 32 -> 16 at 256x256:
+    // 77.5 -> 74.1; whole iteration 7.29 -> 7.25 ms with no threshold at all, which is what stays.
+    const bool small = precision == 0 && Cin <= 32 && Cout <= 32 && p.tw == 32 && p.n_tiles <= NGAN_WGRAD_SMALL;
+    p.co_s = (Cout % 32 == 0 && !small) ? 32 : 16;
+    p.ci_s = (Cin % 32 == 0 && !small) ? 32 : 16;
+    p.n_ci_slices = Cin / p.ci_s;
+    p.nslices = (Cout / p.co_s) * p.n_ci_slices;
     const int forced = NGAN_DIAG_INT("NGAN_WGRAD_SLABS", 0);
     // about two resident workgroups per CU: few slabs to reduce afterwards (256 / 768 measured slower).  The fp32 kernel's 32 x 32
     // slices are 8-wave workgroups with 83 KB of LDS, one per CU: 256 of them (fp32 32 -> 32 at 128x128: 100 vs 106 us, 64 -> 64 at
