@@ -766,11 +766,19 @@ struct ReduceEntry {
 constexpr int kReduceBatch = 24;
 struct ReduceBatch { ReduceEntry e[kReduceBatch]; int n; };
 
-// One workgroup sums kReduceSpan consecutive elements of a gradient over all slabs: a wave reads 256 contiguous bytes of one slab
-// per load (whole cache lines; 16-element spans fetched half-used 128-byte lines), the waves take every 16th slab each.
-// 16 waves per workgroup: a 16-channel layer has 512 slabs per source and only 36 spans, so the launch is bound by the CHAIN of
-// dependent round trips per wave (128 loads, 8 in flight, x 3 sources with 4 waves: ~100 us measured); 16 waves cut the chain by 4.
-constexpr int kReduceSpan = 64, kReduceThreads = 1024;
+// One workgroup of 1024 threads sums a SPAN of consecutive elements of a gradient over all slabs, split into NG slab groups:
+// thread (group g, element e) adds slabs g, g + NG, ... with eight independent partial sums (eight loads in flight), the groups are
+// summed through LDS in a fixed order.  NG is chosen per entry so that a thread has about eight slabs per source: a 16-channel layer
+// (512 slabs, 2 304 elements) takes NG = 16 groups of 64-element spans -- the launch is then bound by the chain of dependent round
+// trips per wave, which 16 groups cut by 16 -- while a 128-channel layer (32 slabs, 147 456 elements) takes NG = 4 groups of 256
+// elements: round 2's fixed NG = 16 gave it 2 304 workgroups of 1 024 threads with TWO loads per thread each and made those layers
+// three quarters of the launch's time.  A wave always reads whole 256-byte runs of one slab.
+constexpr int kReduceThreads = 1024;
+__host__ __device__ inline int reduce_groups(const ReduceEntry& e) {
+    int np = 0;
+    for (int s = 0; s < e.nsrc; ++s) np = e.nparts[s] > np ? e.nparts[s] : np;
+    return np >= 128 ? 16 : np >= 64 ? 8 : np >= 32 ? 4 : np >= 16 ? 2 : 1;
+}
 __global__ __launch_bounds__(kReduceThreads) void wgrad_reduce_many_kernel(ReduceBatch b) {
     __shared__ float red[kReduceThreads];
     int ei = 0;
@@ -779,9 +787,9 @@ __global__ __launch_bounds__(kReduceThreads) void wgrad_reduce_many_kernel(Reduc
     const ReduceEntry& e = b.e[ei];
     const int slab = 9 * e.co_s * e.ci_s;
     const long M = (long)e.nslices * slab;
-    const int tid = threadIdx.x, el = tid & (kReduceSpan - 1), grp = tid / kReduceSpan;
-    constexpr int NG = kReduceThreads / kReduceSpan;
-    const long i = (long)(blockIdx.x - e.first_block) * kReduceSpan + el;
+    const int NG = reduce_groups(e), span = kReduceThreads / NG;
+    const int tid = threadIdx.x, el = tid & (span - 1), grp = tid / span;
+    const long i = (long)(blockIdx.x - e.first_block) * span + el;
     float total = 0.f;
     for (int s = 0; s < e.nsrc; ++s) {
         float acc = 0.f;
@@ -804,14 +812,13 @@ __global__ __launch_bounds__(kReduceThreads) void wgrad_reduce_many_kernel(Reduc
         __syncthreads();
         red[tid] = acc;
         __syncthreads();
-        if (tid < kReduceSpan) {
+        if (tid < span) {
             float t = 0.f;
-#pragma unroll
-            for (int j = 0; j < NG; ++j) t += red[tid + kReduceSpan * j];
+            for (int j = 0; j < NG; ++j) t += red[tid + span * j];
             total = fmaf(t, e.scale[s], total);
         }
     }
-    if (tid < kReduceSpan && i < M) {
+    if (tid < span && i < M) {
         int r = (int)(i % slab);
         const int slice = (int)(i / slab);
         const int ci_l = r % e.ci_s; r /= e.ci_s;
@@ -850,7 +857,7 @@ extern "C" int ngan_conv3x3_wgrad_reduce_many(const void* entries, int n, void* 
             b.e[i] = src[base + i];
             NGAN_REQUIRE(b.e[i].nsrc >= 1 && b.e[i].nsrc <= 4 && b.e[i].gw, NGAN_ERR_ARG, "conv3x3_wgrad_reduce_many: bad entry %d", base + i);
             b.e[i].first_block = blocks;
-            blocks += ngan::ceil_div((long)b.e[i].nslices * 9 * b.e[i].co_s * b.e[i].ci_s, kReduceSpan);
+            blocks += ngan::ceil_div((long)b.e[i].nslices * 9 * b.e[i].co_s * b.e[i].ci_s, kReduceThreads / reduce_groups(b.e[i]));
         }
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(blocks), dim3(kReduceThreads), 0, (hipStream_t)stream, b);
         int st = ngan::launch_status("ngan_conv3x3_wgrad_reduce_many");
