@@ -25,6 +25,9 @@ namespace {
 #ifndef NGAN_TILE_PRE_WINO
 #define NGAN_TILE_PRE_WINO 1
 #endif
+#ifndef NGAN_TILE_DOUBLE_BUFFER
+#define NGAN_TILE_DOUBLE_BUFFER 1
+#endif
 
 template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
 __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_tile_kernel(ConvArgs a, int n_tiles) {
@@ -41,7 +44,11 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
     constexpr int K = KG * 16, N = MTW * 16;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     static_assert(HH_ % 2 == 0 && N_HALO <= 256, "staging layout");
-    __shared__ __attribute__((aligned(16))) float smem[W_ELEMS + TILE_ELEMS];
+    // Winograd instances: TWO tile buffers.  The next tile is staged into the other buffer while this one is being read, so a tile
+    // costs one workgroup barrier instead of two and no wave waits for the others' staging before its MFMAs (16 + 2 x 25.6 KB: still
+    // two workgroups per CU).  The other instances run 3 - 4 workgroups per CU on one buffer.
+    constexpr bool DB = WINO && NGAN_TILE_DOUBLE_BUFFER;
+    __shared__ __attribute__((aligned(16))) float smem[W_ELEMS + (DB ? 2 : 1) * TILE_ELEMS];
     float* wl = smem;
     float* tile = smem + W_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -157,23 +164,40 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
     const float inv_n = 1.0f / (float)N;
     const f32x2 slope2 = {a.slope, a.slope};
 
-    while (t < t_end) {
-        int b, y0, x0;
-        decode(t, b, y0, x0);
-        __syncthreads();   // previous tile's MFMAs have finished reading `tile`
+    auto stage = [&](float* buf) {                 // the loaded tile (stg) -> LDS image
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            if (BF) st_split<KG, PLANE>(tile, s_lds[i], stg[i]);
-            else st4(&tile[s_lds[i]], stg[i]);
+            if (BF) st_split<KG, PLANE>(buf, s_lds[i], stg[i]);
+            else st4(&buf[s_lds[i]], stg[i]);
         }
         pin_registers(stg[NL]);     // every wave awaits the halo load here (the waves that store nothing would carry it, un-awaited, into the next issue)
         if (tid < N_HALO) {
-            if (BF) st_split<KG, PLANE>(tile, s_lds[NL], stg[NL]);
-            else st4(&tile[s_lds[NL]], stg[NL]);
+            if (BF) st_split<KG, PLANE>(buf, s_lds[NL], stg[NL]);
+            else st4(&buf[s_lds[NL]], stg[NL]);
         }
+    };
+    if (DB && t < t_end) {                         // double-buffered: the first tile is staged here, the second one's loads go out
+        stage(tile);
         __syncthreads();
+        if (t + run.step < t_end) issue(t + run.step);
+    }
+    float* const tile0 = tile;
+    int cur = 0;
+    while (t < t_end) {
+        int b, y0, x0;
+        decode(t, b, y0, x0);
         const int tn = t + run.step;
-        if (tn < t_end) issue(tn);   // in flight while this tile is computed
+        if (DB) {
+            // stg holds tile tn (loaded during the previous tile): into the buffer nobody reads now; then the loads of the tile after it
+            tile = tile0 + cur * TILE_ELEMS;
+            if (tn < t_end) stage(tile0 + (cur ^ 1) * TILE_ELEMS);
+            if (tn + run.step < t_end) issue(tn + run.step);
+        } else {
+            __syncthreads();   // previous tile's MFMAs have finished reading `tile`
+            stage(tile);
+            __syncthreads();
+            if (tn < t_end) issue(tn);   // in flight while this tile is computed
+        }
 
         // ---- per-tile scalars of the epilogue.  The tile's byte offset is ADDED to the per-lane constants (one v_add per access)
         // instead of riding in the buffer instructions' soffset field: a buffer_store_dwordx4 with an SGPR soffset reads its data
@@ -458,6 +482,10 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
             const float tv = tanhf(timg);
             const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.aout + img, 0, px_bytes, 0x00020000);
             if (q < PGW) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), t_rsrc, t_voff + p_soff, 0, 0);
+        }
+        if (DB) {
+            __syncthreads();   // every wave has finished reading this tile's buffer and writing the next tile's
+            cur ^= 1;
         }
         t = tn;
     }
