@@ -26,7 +26,7 @@ namespace {
 #define NGAN_TILE_PRE_WINO 1
 #endif
 #ifndef NGAN_TILE_DOUBLE_BUFFER
-#define NGAN_TILE_DOUBLE_BUFFER 1
+#define NGAN_TILE_DOUBLE_BUFFER 0      // measured, round 3: slower (below)
 #endif
 
 template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
@@ -44,9 +44,11 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
     constexpr int K = KG * 16, N = MTW * 16;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     static_assert(HH_ % 2 == 0 && N_HALO <= 256, "staging layout");
-    // Winograd instances: TWO tile buffers.  The next tile is staged into the other buffer while this one is being read, so a tile
-    // costs one workgroup barrier instead of two and no wave waits for the others' staging before its MFMAs (16 + 2 x 25.6 KB: still
-    // two workgroups per CU).  The other instances run 3 - 4 workgroups per CU on one buffer.
+    // Build-time option for the Winograd instances: TWO tile buffers.  The next tile is staged into the other buffer while this one
+    // is being read, so a tile costs one workgroup barrier instead of two and no wave waits for the others' staging before its MFMAs
+    // (16 + 2 x 25.6 KB: still two workgroups per CU).  Correct (the whole op suite passes with it) and NOT faster: 16 -> 16 at
+    // 512 x 512, batch 16: 145 -> 154 us plain, 165 -> 167 us with LeakyReLU -> PixelNorm, 75.9 -> 80.4 us with the pool-adjoint store;
+    // iteration 7.17 -> 7.22 ms.  The second barrier was not what the waves wait for; off.
     constexpr bool DB = WINO && NGAN_TILE_DOUBLE_BUFFER;
     __shared__ __attribute__((aligned(16))) float smem[W_ELEMS + (DB ? 2 : 1) * TILE_ELEMS];
     float* wl = smem;
