@@ -611,6 +611,64 @@ def test_winograd_kernels_against_fp64(ngan, shape, kn):
         assert float((aout.cpu().double() - t).abs().max()) < 2e-5
 
 
+FULL_SIZE_LAYERS = [  # B, H, W, Cin, Cout, resample: layers of the 512x512 final stage at BASELINE.json's batch 16 (and 32: the critic step)
+    (16, 512, 512, 16, 16, 0), (32, 512, 512, 16, 16, 2), (16, 256, 256, 32, 16, 2), (32, 256, 256, 16, 16, 1), (32, 128, 128, 16, 32, 1),
+    (32, 128, 128, 32, 32, 0), (16, 128, 128, 32, 32, 2), (32, 64, 64, 32, 32, 1), (32, 32, 32, 64, 64, 0), (32, 16, 16, 128, 128, 0),
+]
+
+
+@pytest.mark.parametrize("layer", FULL_SIZE_LAYERS)
+def test_full_size_layers_satisfy_the_adjoint_identities(ngan, layer, conv_precision):
+    """At BASELINE.json's full sizes an fp64 reference of a layer takes minutes on the CPU; the convolution triple is checked there
+    through identities that hold for ANY correct implementation and need no reference:  <conv(x; W), g> = <x, dgrad(g; W)> =
+    <W, wgrad(x, g)>  (the three kernels compute the three partial derivatives of one trilinear form).  The inner products are
+    accumulated in fp64 on the GPU; the three numbers must agree to 2e-5 of their magnitude (random fp32 operands, ~1e7 terms).  A wrong
+    tile offset, a 32-bit overflow or a dropped border anywhere in an image shows up here; the small cases elsewhere pin the values."""
+    B, H, W, Cin, Cout, res = layer
+    ops = ngan.ops
+    torch.manual_seed(B + H + Cin + 7 * Cout + res)
+    hin, win = (2 * H, 2 * W) if res == 1 else ((H // 2, W // 2) if res == 2 else (H, W))
+    x = torch.randn(B, hin, win, Cin, device=DEV)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV)
+    g = torch.randn(B, H, W, Cout, device=DEV)
+    scale = 1.0 / np.sqrt(9 * Cin)
+    y = ops.Conv.apply(x, w, None, res, scale)
+    gx = ops.ConvDgrad.apply(g, w, res, scale)
+    gw = ops.ConvWgrad.apply(x, g, res, scale)
+    assert y.shape == g.shape and gx.shape == x.shape and gw.shape == w.shape
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    a0, a1, a2 = dot(y, g), dot(x, gx), dot(w, gw)
+    mag = float(y.double().norm() * g.double().norm())
+    assert abs(a0 - a1) < 2e-5 * mag and abs(a0 - a2) < 2e-5 * mag, (a0, a1, a2, mag)
+
+
+@pytest.mark.parametrize("shape", [(16, 512, 512, 16), (32, 128, 128, 32), (32, 16, 16, 128)])
+def test_full_size_pixelnorm_properties(ngan, shape):
+    """LeakyReLU -> PixelNorm at BASELINE.json's sizes through properties that need no reference (models.py:118-126, 263):
+    forward  y * r = LeakyReLU(c) and mean_c(y^2) = 1 - eps / r^2;  backward  sum_c (gc / m) * y = 0 per pixel (the gradient w.r.t. the
+    pre-activation, with the LeakyReLU slope divided out, is orthogonal to y: PixelNorm's output does not change along y);
+    backward-of-backward: the same orthogonality for the term that is linear in the incoming second-order gradient."""
+    B, H, W, C = shape
+    ops = ngan.ops
+    torch.manual_seed(C + H)
+    c = torch.randn(B, H, W, C, device=DEV)
+    y, r = ops.LReLUPN.apply(c, None, SLOPE)
+    lre = torch.where(c > 0, c, SLOPE * c)
+    assert float((y * r.unsqueeze(-1) - lre).abs().max()) < 1e-5
+    assert float(((y.double() ** 2).mean(-1) - 1.0).abs().max()) < 1e-5
+    gy = torch.randn_like(y)
+    gc = ops.LReLUPNBwd.apply(gy, None, y, r, SLOPE)
+    m = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, SLOPE))
+    ortho = ((gc.double() / m.double()) * y.double()).sum(-1)
+    scale = float(gy.double().norm(dim=-1).mean() / r.double().mean())
+    assert float(ortho.abs().max()) < 1e-4 * scale * np.sqrt(C), (float(ortho.abs().max()), scale)
+    h = torch.randn_like(y)
+    ggy = torch.empty_like(y); gy_out = torch.empty_like(y); gr_out = torch.empty_like(r)
+    ngan._C.call("ngan_lrelu_pixelnorm_bwdbwd", h, gy, y, r, ggy, gy_out, gr_out, y.numel() // C, C, SLOPE)
+    ortho2 = (ggy.double() * y.double()).sum(-1)          # ggy = (m h - y mean_c(m h y)) / r is orthogonal to y as well
+    assert float(ortho2.abs().max()) < 1e-4 * scale * np.sqrt(C)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 16, 16, 0), (1, 64, 64, 32, 32, 0), (2, 8, 8, 64, 64, 0), (1, 32, 64, 16, 32, 1), (2, 32, 32, 32, 16, 2),
                                   (4, 16, 16, 128, 128, 0),                                        # 128 channels (mid kernel, channels split over workgroups)
                                   (2, 128, 256, 16, 16, 0), (2, 128, 256, 32, 32, 0), (2, 128, 256, 16, 32, 0), (2, 128, 256, 32, 16, 0),   # Winograd-eligible
