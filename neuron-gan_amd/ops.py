@@ -33,8 +33,15 @@ EPI_NONE, EPI_LRELU_PN, EPI_PN_BWD, EPI_TO_IMAGE = 0, 1, 2, 3      # epilogues o
 # then lets the consumer's input-gradient kernel apply the producer's LeakyReLU->PixelNorm backward in its epilogue: the gradient
 # w.r.t. the producer's output is never written and re-read, and the producer's own PixelNorm-backward launch disappears.
 # ---------------------------------------------------------------------------------------------------------
+def _diag_env(name, default):
+    """Measurement A/B switches are honoured only with NGAN_DIAG=1 in the environment (tools/ab_env.sh sets it): a stray variable must
+    not change which kernels a training run or a parity test exercises.  (The documented user knobs are NGAN_CONV_PRECISION and
+    NGAN_LIB_PATH; the kernel library itself reads no environment variable.)"""
+    return os.environ.get(name, default) if os.environ.get("NGAN_DIAG") == "1" else default
+
+
 _first_order = 0
-_first_order_allowed = os.environ.get("NGAN_FIRST_ORDER_FUSION", "1") != "0"     # A/B switch for measurements and tests
+_first_order_allowed = _diag_env("NGAN_FIRST_ORDER_FUSION", "1") != "0"     # A/B switch for measurements and tests
 
 
 def allow_first_order_fusion(flag):
@@ -244,8 +251,8 @@ def _pool_first(resample):
     return resample == RES_POOL2 and _conv_precision == 0 and _pool_first_allowed
 
 
-_pool_first_allowed = os.environ.get("NGAN_POOL_FIRST", "1") != "0"     # A/B switch for measurements and tests
-_pool_out_allowed = os.environ.get("NGAN_POOL_OUT", "1") != "0"         # A/B switch: pooled side output of the producing conv
+_pool_first_allowed = _diag_env("NGAN_POOL_FIRST", "1") != "0"     # A/B switch for measurements and tests
+_pool_out_allowed = _diag_env("NGAN_POOL_OUT", "1") != "0"         # A/B switch: pooled side output of the producing conv
 
 
 def _pooled(x):
@@ -387,7 +394,7 @@ class deferred_wgrad:
 
 
 # A/B switch (off by default: measured): weight gradients of layers with at most this many pixels go to a side stream
-_side_wgrad_pixels = int(os.environ.get("NGAN_WGRAD_SIDE_PIXELS", "0"))
+_side_wgrad_pixels = int(_diag_env("NGAN_WGRAD_SIDE_PIXELS", "0"))
 _side_stream = None
 _side_keep = []
 
@@ -787,7 +794,7 @@ class FromImage(Function):
         return gx, gw, gb, None
 
 
-_first_block_allowed = os.environ.get("NGAN_FIRST_BLOCK", "1") != "0"      # A/B switch for measurements
+_first_block_allowed = _diag_env("NGAN_FIRST_BLOCK", "1") != "0"      # A/B switch for measurements
 
 
 def first_block_fusable(x, w_from, w_conv):

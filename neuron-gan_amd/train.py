@@ -483,7 +483,7 @@ class PGGANTrainer:
         # capture mode refuses such a call from ANY thread while a capture is active (hipErrorStreamCaptureUnsupported -> the
         # watchdog terminates the process); thread_local polices the capturing thread only.  The second rule (an event whose stream
         # is part of the capture) is what _on_comm_stream takes care of.  Both reproduced case by case: tools/capture_event_probe.py.
-        mode = os.environ.get("NGAN_CAPTURE_MODE") or ("thread_local" if self._comm_stream is not None else "global")
+        mode = ops._diag_env("NGAN_CAPTURE_MODE", "") or ("thread_local" if self._comm_stream is not None else "global")
         # No cyclic garbage collection while a capture is active: a collection that happens to start inside the captured region runs
         # the finalizers of whatever cyclic garbage earlier code left behind (graphs of a previous stage or trainer, events, tensors
         # of released graph pools) on the capturing thread, and HIP aborts the process for some of those calls during a global-mode
