@@ -24,6 +24,13 @@
 // Staging, descriptors, padding by whole load instructions and the epilogue arithmetic are those of conv3x3_tile_kernel.
 #include "conv3x3_internal.h"
 
+#ifndef NGAN_WINO_STAGGER
+#define NGAN_WINO_STAGGER 0
+#endif
+#ifndef NGAN_WINO_PRIO
+#define NGAN_WINO_PRIO 0
+#endif
+
 namespace {
 
 template <int KG, int MT, int ROWS, int NWAVES, int RES, int EPI, int OUTMODE>
@@ -65,6 +72,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
     const int cb = nh * MTW * 16;                                 // first output channel of this wave
 
     for (int e = tid; e < W_ELEMS / 4; e += NT) st4(wl + e * 4, ld4(a.wp + e * 4));
+#if NGAN_WINO_PRIO
+    if (NWAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);      // experiment: static priority for the later-dispatched half
+#endif
 
     const TileRun run = tile_run(n_tiles);
     int t = run.t;
@@ -214,6 +224,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
             if (tid < N_HALO) st4(&tile[s_lds[NL]], stg[NL]);
         }
         __syncthreads();
+#if NGAN_WINO_STAGGER
+        if (NS > 1 && nh) __builtin_amdgcn_s_sleep(NGAN_WINO_STAGGER);   // experiment: offset the two waves that share a SIMD and a tile row
+#endif
         const int tn = t + run.step;
         if (tn < t_end) issue(tn);   // in flight while this tile is computed
 
