@@ -40,6 +40,36 @@ def test_invalid_arguments_return_status_not_crash(built):
     assert built._C.wgrad_workspace_bytes(1, 8, 8, 12, 16) == 0
 
 
+def test_wide_layers_are_cut_into_kernel_sized_chunks(ngan):
+    """A conv launch takes 16 / 32 / 64 / 128 output channels (include/ngan.h); the reference's wide presets (configs/config.py:87-98)
+    and any other multiple of 16 run as chunks of those sizes, largest first, covering every channel exactly once."""
+    chunks = ngan.ops._n_chunks
+    assert chunks(128) == [(0, 128)] and chunks(16) == [(0, 16)]
+    assert chunks(256) == [(0, 128), (128, 128)] and chunks(1024) == [(i * 128, 128) for i in range(8)]
+    assert chunks(48) == [(0, 32), (32, 16)] and chunks(240) == [(0, 128), (128, 64), (192, 32), (224, 16)]
+    for n in range(16, 1040, 16):
+        c = chunks(n)
+        assert sum(k for _, k in c) == n and all(k in (16, 32, 64, 128) for _, k in c)
+        assert [s0 for s0, _ in c] == [sum(k for _, k in c[:i]) for i in range(len(c))]
+    with pytest.raises(RuntimeError):
+        chunks(24)
+
+
+def test_measurement_switches_need_the_diag_flag(ngan, monkeypatch):
+    """The Python layer's A/B switches are honoured only with NGAN_DIAG=1: a stray environment variable must not change which
+    kernels a run exercises (the kernel library reads no environment variable at all: csrc/conv3x3_internal.h)."""
+    monkeypatch.delenv("NGAN_DIAG", raising=False)
+    monkeypatch.setenv("NGAN_POOL_FIRST", "0")
+    assert ngan.ops._diag_env("NGAN_POOL_FIRST", "1") == "1"
+    monkeypatch.setenv("NGAN_DIAG", "1")
+    assert ngan.ops._diag_env("NGAN_POOL_FIRST", "1") == "0"
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "neuron-gan_amd", "csrc", "*")):
+        if f.endswith((".hip", ".cpp", ".h")):
+            src = open(f).read()
+            assert "getenv" not in src or "conv3x3_internal.h" in f, f"{f} reads the environment"
+
+
 def test_no_cpu_fallback(ngan):
     G = ngan.models.Generator_PG([32, 16], image_size_init=4, latent_dim=32)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
