@@ -30,6 +30,9 @@ struct WgradArgs {
 #ifndef NGAN_WGRAD_W22
 #define NGAN_WGRAD_W22 8
 #endif
+#ifndef NGAN_WGRAD_WINO16
+#define NGAN_WGRAD_WINO16 1
+#endif
 #ifndef NGAN_WGRAD_SMALL
 #define NGAN_WGRAD_SMALL (1 << 30)
 #endif
@@ -47,7 +50,9 @@ constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }
 // format, slab reduction and bit-reproducibility are those of the direct form.
 template <int COT, int CIT, int RES, int TW, int NW, int XF, int WINO = 0>
 __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 || NW == 4 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
-    static_assert(!WINO || TW == 32, "Winograd weight gradient: 8 x 32 tiles (a wave takes whole rows of 16 tiles)");
+    // Winograd form: a wave step covers 16 Winograd tiles -- one row of an 8 x 32 tile, or (TW = 16: images at most 16 pixels wide)
+    // two rows of 8 of a 16 x 16 tile, lane quarters q = 0, 1 on the upper and q = 2, 3 on the lower row
+    constexpr int WSTEP_ROWS = TW == 32 ? 2 : 4;                 // output rows a wave step covers
     constexpr int NT = NW * 64;
     constexpr int TH = 256 / TW, HALO_H = TH + 2, NBLK = TW / 16;
     constexpr int CO_S = COT * 16, CI_S = CIT * 16;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
     constexpr int CW = SHARE ? COT : 1;                          // output groups per wave
     constexpr int WQ = (COT / CW) * CIT;                         // wave groups over (output group sets, input groups)
     constexpr int WRW = NW / WQ, RPWW = TH / WRW;                // Winograd: row groups, rows per wave
-    static_assert(!WINO || (NW % WQ == 0 && TH % WRW == 0 && RPWW % 2 == 0), "Winograd wave split");
+    static_assert(!WINO || (NW % WQ == 0 && TH % WRW == 0 && RPWW % WSTEP_ROWS == 0), "Winograd wave split");
     // the 16 positions cross the waves in four passes of 4 (virtual wave = (row group, sub-slice)); the back-transform needs 12 per item
     constexpr int RED_WINO = (WRW * WO * 4 > WO * 12 ? WRW * WO * 4 : WO * 12) * 64 * 4;
     constexpr int RED_ELEMS = WINO ? RED_WINO : NW * 9 * 64 * 4;
@@ -267,10 +272,10 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
             // lane (p, q) owns the four consecutive tiles 4 q .. 4 q + 3 of the row (K-step ks contracts tiles 4 q + ks over q): two tiles
             // at a time are one 16-byte + one 8-byte read per input row and one 16-byte read per gradient row and output group
 #pragma unroll
-            for (int tr = 0; tr < RPWW / 2; ++tr) {
-            const int row0 = wrw * RPWW + 2 * tr;
-            const float* gp = g_lds + (cot0w * 16 + p) * PLANE_G + row0 * TW + 8 * q;       // + c * 16 * PLANE_G per output group
-            const float* xp = x_lds + (citw * 16 + p) * PLANE_X + row0 * XP + 8 * q;
+            for (int tr = 0; tr < RPWW / WSTEP_ROWS; ++tr) {
+            const int row0 = wrw * RPWW + WSTEP_ROWS * tr + (TW == 32 ? 0 : 2 * (q >> 1)), col0 = 8 * (TW == 32 ? q : (q & 1));
+            const float* gp = g_lds + (cot0w * 16 + p) * PLANE_G + row0 * TW + col0;       // + c * 16 * PLANE_G per output group
+            const float* xp = x_lds + (citw * 16 + p) * PLANE_X + row0 * XP + col0;
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
                 float xr[4][6], gr[CW][2][4];
@@ -713,6 +718,12 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision,
         return ngan::launch_status("ngan_conv3x3_wgrad(bf16x3, 16x16 tiles)");
     }
     constexpr int NW = wgrad_f32_waves(COT, CIT);
+    if (wgrad_wino_on() && p.tw == 16 && NGAN_WGRAD_WINO16) {
+        if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 16, NW, 0, 1>), grid, dim3(NW * 64), 0, s, a);
+        else if (res == 1) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 1, 16, NW, 0, 1>), grid, dim3(NW * 64), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 2, 16, NW, 0, 1>), grid, dim3(NW * 64), 0, s, a);
+        return ngan::launch_status("ngan_conv3x3_wgrad(f32, winograd, 16 x 16 tiles)");
+    }
     if (wgrad_wino_on() && p.tw == 32) {
         if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 1, 1>), grid, dim3(NW * 64), 0, s, a);
         else if (res == 0) hipLaunchKernelGGL((wgrad_f32_kernel<COT, CIT, 0, 32, NW, 0, 1>), grid, dim3(NW * 64), 0, s, a);
@@ -744,7 +755,7 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
     if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
     else {
-        const bool wino = wgrad_wino_on() && p.tw == 32;
+        const bool wino = wgrad_wino_on() && (p.tw == 32 || NGAN_WGRAD_WINO16);
         snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw,
                  wgrad_f32_waves(p.co_s / 16, p.ci_s / 16), (resample == 0 && p.tw == 32 && W % 32 == 0) ? 1 : 0, wino ? 1 : 0);
     }
