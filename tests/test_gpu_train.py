@@ -177,6 +177,38 @@ def test_cached_graphs_of_two_shapes_replay_the_eager_trajectory(ngan):
         assert torch.equal(p, pe), f"{name}: {float((p - pe).abs().max())}"
 
 
+def test_wide_nets_through_the_step_driver(ngan):
+    """Blocks wider than 128 channels (the reference's presets 0004-0008) run as output-channel chunks with one-shot packed weight
+    slices (ops._n_chunks): the whole step driver -- flat buffers, fused Adam, graph capture and replay -- must take them, and the
+    replayed trajectory must equal the eager one bit for bit."""
+    def make():
+        torch.manual_seed(21)
+        G = ngan.models.Generator_PG([256, 128], image_size_init=8, latent_dim=32)
+        D = ngan.models.Discriminator_PG([128, 256], image_size_init=8)
+        G.set_resolution(16, 0.5)
+        D.set_resolution(16, 0.5)
+        return ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), learning_rate=1e-3)
+    gen = torch.Generator().manual_seed(5)
+    def draw(b):
+        z = [torch.randn(b, 32, generator=gen) for _ in range(3)]
+        z = [(v / v.norm(dim=1, keepdim=True)).to(DEV) for v in z]
+        return dict(real=(torch.rand(b, 1, 16, 16, generator=gen) * 2 - 1).to(DEV), z_d=z[0], z_gp=z[1],
+                    eps=torch.rand(b, 1, 1, 1, generator=gen).to(DEV), z_g=z[2])
+    seq = [draw(4) for _ in range(3)]
+    eager, tr = make(), make()
+    static = {k: seq[0][k].clone() for k in ("z_d", "z_gp", "eps", "z_g")}
+    tr.capture(seq[0]["real"], draws=static)
+    for s in seq:
+        stats = eager.train_iteration(s["real"], s["z_d"], s["z_gp"], s["eps"], s["z_g"])
+        for k, v in static.items():
+            v.copy_(s[k])
+        tr.replay(s["real"])
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(v)) for v in stats.values())
+    for name, p, pe in zip(tr.flat_g.names + tr.flat_d.names, tr.flat_g.params + tr.flat_d.params, eager.flat_g.params + eager.flat_d.params):
+        assert torch.equal(p, pe), f"{name}: {float((p - pe).abs().max())}"
+
+
 def test_penalty_switched_off_draws_no_second_latent_batch(ngan):
     """grad_pen_lambda = 0 is the reference CLI's argparse default: D_grad_pen_loss returns 0 (loss_functions.py:179) and draws
     nothing.  The step driver must run (round 1 stacked a CPU scalar with device tensors) and must not generate the unused fakes."""
