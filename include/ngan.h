@@ -162,6 +162,10 @@ int ngan_lrelu_pixelnorm_bwdbwd(const float* h, const float* gy, const float* y,
 
 /* column sums over pixels: out[c] = scale * sum_p g[p][c]   (bias gradient of conv2d).  workspace: 1024*C floats */
 int ngan_channel_sum(const float* g, float* out, float* workspace, long npix, int C, float scale, void* stream);
+/* Small parameter gradients added straight into an existing gradient buffer (the step driver's flat .grad views) instead of being
+ * returned and added by a separate elementwise launch: the `_acc` forms take `accumulate`, a bit mask over the function's outputs
+ * (bit i set: output i is added into, clear: written).  channel_sum: out (bit 0). */
+int ngan_channel_sum_acc(const float* g, float* out, float* workspace, long npix, int C, float scale, int accumulate, void* stream);
 
 /* ---- FromImage 1x1 conv + bias: models.py:161-165 ---------------------------------------------------------------
  * fwd: y[p][c] = sum_k w[c][k]*x[p][k] + b[c];  pool=1: x is (B,2H,2W,Ncol) and is 2x2-averaged on load (models.py:519)
@@ -172,6 +176,8 @@ int ngan_from_image_fwd(const float* x, const float* w, const float* b, float* y
 int ngan_from_image_dx(const float* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool, void* stream);
 int ngan_from_image_dw(const float* x, const float* g, float* gw, float* gb, float* workspace,
                        int B, int H, int W, int Ncol, int C, int pool, void* stream);
+int ngan_from_image_dw_acc(const float* x, const float* g, float* gw, float* gb, float* workspace,
+                           int B, int H, int W, int Ncol, int C, int pool, int accumulate, void* stream);   /* accumulate: bit 0 gw, bit 1 gb */
 
 /* ---- ToImage 1x1 conv + tanh: models.py:141-149 ------------------------------------------------------------------
  * fwd: t[p][k] = tanh(sum_c w[k][c]*x[p][c])
@@ -183,6 +189,8 @@ int ngan_to_image_bwd(const float* g, const float* t, const float* x, const floa
  * that operator's input, i.e. the PixelNorm/LeakyReLU backward is applied before the store (one pass over the activation) */
 int ngan_to_image_bwd_pnbwd(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
                             float* gw, float* workspace, long npix, int C, int Ncol, float slope, void* stream);
+int ngan_to_image_bwd_pnbwd_acc(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
+                                float* gw, float* workspace, long npix, int C, int Ncol, float slope, int accumulate, void* stream);   /* accumulate != 0: gw += */
 
 /* ---- resampling: models.py:87-89 (F.interpolate bilinear, align_corners=None) and models.py:254 (AvgPool2d(2)) --
  * (h, w) is always the LOW resolution; adjoint = transpose of the linear map. */
@@ -245,6 +253,8 @@ int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, int B, int K,
 int ngan_final_dot_fwd(const float* y, const float* W, const float* bias, float* out, int B, int S2, int C, float scale, void* stream);
 int ngan_final_dot_dx(const float* go, const float* W, float* gy, int B, int S2, int C, float scale, void* stream);
 int ngan_final_dot_dw(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, void* stream);
+int ngan_final_dot_dw_acc(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, int accumulate,
+                          void* stream);                                   /* accumulate: bit 0 gW, bit 1 gb */
 
 /* ---- Adam: optim.Adam.step, train.py:224-225, 366, 385 (betas (beta1, 0.999), eps 1e-8, no weight decay) ---------
  * One launch updates every active segment of a flat parameter buffer.
@@ -273,7 +283,7 @@ int ngan_first_block_fwd(const float* p, const float* w_conv, const float* wf, c
 size_t ngan_first_block_workspace_floats(int B, int H, int N);
 int ngan_first_block_bwd(const float* p, const float* gc, const float* w_conv, const float* wf, const float* bf,
                          float* gw_conv, float* gwf, float* gbf, float* gb_conv, float* workspace, int B, int H, int W, int C,
-                         int N, float scale, int accumulate, void* stream);
+                         int N, float scale, int accumulate, void* stream);   /* accumulate: bit 0 gw_conv, 1 gwf, 2 gbf, 3 gb_conv */
 int ngan_first_block_dx(const float* gc, const float* tables, float* gx, int B, int H, int W, int N, int pool, void* stream);
 
 /* ---- on-device input pipeline: data/NeuronDataset.py:112-126, 149-164 (torchvision RandomAffine / RandomVerticalFlip /

@@ -25,12 +25,15 @@ SIGNATURES = {
     "ngan_lrelu_pixelnorm_bwd2": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P],
     "ngan_lrelu_pixelnorm_bwdbwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P],
     "ngan_channel_sum": [_P, _P, _P, _L, _I, _F, _P],
+    "ngan_channel_sum_acc": [_P, _P, _P, _L, _I, _F, _I, _P],
     "ngan_from_image_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ngan_from_image_dx": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ngan_from_image_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ngan_from_image_dw_acc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ngan_to_image_fwd": [_P, _P, _P, _L, _I, _I, _P],
     "ngan_to_image_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "ngan_to_image_bwd_pnbwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P],
+    "ngan_to_image_bwd_pnbwd_acc": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P],
     "ngan_up2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "ngan_up2_adjoint": [_P, _P, _I, _I, _I, _I, _P],
     "ngan_up2_adjoint_pnbwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
@@ -54,6 +57,7 @@ SIGNATURES = {
     "ngan_final_dot_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "ngan_final_dot_dx": [_P, _P, _P, _I, _I, _I, _F, _P],
     "ngan_final_dot_dw": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "ngan_final_dot_dw_acc": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "ngan_conv3x3_pack_many": [_P, _I, _L, _P],
     "ngan_conv3x3_wgrad_reduce_many": [_P, _I, _P],
     "ngan_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void first_block_sums_kernel(const float* __re
 }
 
 // from the summed tables: weight.grad (+)= gW, the conv bias gradient, and the FromImage gradients.  One block.
+// accumulate: bit 0 gW += , bit 1 gwf += , bit 2 gbf += , bit 3 gbc +=  (each output written or added into, e.g. straight into a .grad buffer)
 __global__ __launch_bounds__(256) void first_block_finish_kernel(const float* __restrict__ S, const float* __restrict__ W,
                                                                  const float* __restrict__ wf, const float* __restrict__ bf,
                                                                  float* __restrict__ gW, float* __restrict__ gwf, float* __restrict__ gbf,
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void first_block_finish_kernel(const float* __
     for (int e = threadIdx.x; e < N * C * 9; e += blockDim.x) {
         const int t = e % 9, c = (e / 9) % C, n = e / (9 * C);
         const float v = scale * (wf[c] * S1[t * N + n] + (bf ? bf[c] : 0.f) * S0[t * N + n]);
-        gW[e] = accumulate ? gW[e] + v : v;
+        gW[e] = (accumulate & 1) ? gW[e] + v : v;
     }
     // FromImage gradients: 16 lanes share one channel c (each takes every 16th of the N*9 products), 16 channels per pass
     for (int c0 = 0; c0 < C; c0 += 16) {
@@ -188,12 +189,12 @@ __global__ __launch_bounds__(256) void first_block_finish_kernel(const float* __
         a = group_sum<16>(a);
         b = group_sum<16>(b);
         if (c < C && part == 0) {
-            gwf[c] = a * scale;
-            if (gbf) gbf[c] = b * scale;
+            gwf[c] = (accumulate & 2) ? gwf[c] + a * scale : a * scale;
+            if (gbf) gbf[c] = (accumulate & 4) ? gbf[c] + b * scale : b * scale;
         }
     }
     if (gbc)                                                    // conv bias: sum over pixels of gc = S0 at the centre tap
-        for (int n = threadIdx.x; n < N; n += blockDim.x) gbc[n] = S0[4 * N + n];
+        for (int n = threadIdx.x; n < N; n += blockDim.x) gbc[n] = (accumulate & 8) ? gbc[n] + S0[4 * N + n] : S0[4 * N + n];
 }
 
 __device__ __forceinline__ void fb_load3x4(const float* __restrict__ g, int sy, int xx, int H, int Wd, int N, float4 (&o)[3]) {

@@ -246,19 +246,19 @@ __global__ void final_dot_dx_kernel(const float* __restrict__ go, const float* _
 }
 
 __global__ void final_dot_dw_kernel(const float* __restrict__ y, const float* __restrict__ go, float* __restrict__ gW,
-                                    float* __restrict__ gb, int B, int S2, int C, float scale) {
-    const long n = (long)S2 * C;
+                                    float* __restrict__ gb, int B, int S2, int C, float scale, int accumulate) {
+    const long n = (long)S2 * C;                          // accumulate: bit 0 gW += , bit 1 gb +=
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int p = (int)(i % S2);
         const int c = (int)(i / S2);
         float s = 0.f;
         for (int b = 0; b < B; ++b) s = fmaf(go[b], y[(long)b * n + (long)p * C + c], s);
-        gW[i] = s * scale;
+        gW[i] = (accumulate & 1) ? gW[i] + s * scale : s * scale;
     }
     if (gb && blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += go[b];
-        gb[0] = s;
+        gb[0] = (accumulate & 2) ? gb[0] + s : s;
     }
 }
 
@@ -340,8 +340,13 @@ extern "C" int ngan_final_dot_dx(const float* go, const float* W, float* gy, int
     return ngan::launch_status("ngan_final_dot_dx");
 }
 
-extern "C" int ngan_final_dot_dw(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, void* stream) {
+extern "C" int ngan_final_dot_dw_acc(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, int accumulate,
+                                     void* stream) {
     NGAN_REQUIRE(y && go && gW && B > 0 && S2 > 0 && C > 0, NGAN_ERR_ARG, "final_dot_dw: bad argument");
-    hipLaunchKernelGGL(final_dot_dw_kernel, dim3(ew_blocks((long)S2 * C)), dim3(256), 0, (hipStream_t)stream, y, go, gW, gb, B, S2, C, scale);
+    hipLaunchKernelGGL(final_dot_dw_kernel, dim3(ew_blocks((long)S2 * C)), dim3(256), 0, (hipStream_t)stream, y, go, gW, gb, B, S2, C, scale, accumulate);
     return ngan::launch_status("ngan_final_dot_dw");
+}
+
+extern "C" int ngan_final_dot_dw(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, void* stream) {
+    return ngan_final_dot_dw_acc(y, go, gW, gb, B, S2, C, scale, 0, stream);
 }

@@ -33,6 +33,8 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // stage-2 of every two-stage reduction: out[i] = scale * sum_j partials[j*M + i]
 int reduce_partials(const float* partials, int nparts, int M, float* out, float scale, hipStream_t s);
+int reduce_partials_acc(const float* partials, int nparts, int M, long stride, float* out, int M1, float* out2, float scale, int accumulate,
+                        hipStream_t s);          // accumulate: bit 0 out += , bit 1 out2 +=
 int reduce_partials_split(const float* partials, int nparts, int M, long stride, float* out, int M1, float* out2, float scale,
                           hipStream_t s);
 

@@ -10,7 +10,7 @@ namespace ngan {
 // parts l, l + 64, ... (independent loads, all in flight), then a butterfly over the wave: fixed order, deterministic.
 __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int M,
                                                              long stride, float* __restrict__ out, int M1,
-                                                             float* __restrict__ out2, float scale) {
+                                                             float* __restrict__ out2, float scale, int accumulate = 0) {
     const int i = blockIdx.x, lane = threadIdx.x;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int j = lane;
@@ -22,9 +22,9 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __rest
     }
     for (; j < nparts; j += 64) s0 += partials[(long)j * stride + i];
     const float s = group_sum<64>((s0 + s1) + (s2 + s3));
-    if (lane == 0) {
-        if (i < M1) out[i] = s * scale;
-        else out2[i - M1] = s * scale;
+    if (lane == 0) {            // accumulate: bit 0 out += , bit 1 out2 +=
+        if (i < M1) out[i] = (accumulate & 1) ? out[i] + s * scale : s * scale;
+        else out2[i - M1] = (accumulate & 2) ? out2[i - M1] + s * scale : s * scale;
     }
 }
 
@@ -36,6 +36,12 @@ int reduce_partials_strided(const float* partials, int nparts, int M, long strid
 int reduce_partials_split(const float* partials, int nparts, int M, long stride, float* out, int M1, float* out2, float scale,
                           hipStream_t s) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(M), dim3(64), 0, s, partials, nparts, M, stride, out, M1, out2, scale);
+    return launch_status("reduce_partials");
+}
+
+int reduce_partials_acc(const float* partials, int nparts, int M, long stride, float* out, int M1, float* out2, float scale, int accumulate,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(M), dim3(64), 0, s, partials, nparts, M, stride, out, M1, out2, scale, accumulate);
     return launch_status("reduce_partials");
 }
 
@@ -644,9 +650,12 @@ extern "C" int ngan_gp_coef(const float* norms, int B, float lambda, const float
 }
 
 
-extern "C" int ngan_channel_sum(const float* g, float* out, float* workspace, long npix, int C, float scale, void* stream) {
+extern "C" int ngan_channel_sum_acc(const float* g, float* out, float* workspace, long npix, int C, float scale, int accumulate, void* stream) {
     NGAN_REQUIRE(g && out && workspace, NGAN_ERR_ARG, "channel_sum: null pointer");
-    if (npix > 0 && C > 0 && !pow2_quads(C)) return ngan::wide_channel_sum(g, out, npix, C, scale, (hipStream_t)stream);     // wide.hip
+    if (npix > 0 && C > 0 && !pow2_quads(C)) {                                                                                    // wide.hip
+        NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "channel_sum: accumulate is not available for C=%d", C);
+        return ngan::wide_channel_sum(g, out, npix, C, scale, (hipStream_t)stream);
+    }
     NGAN_REQUIRE(npix > 0 && pow2_quads(C), NGAN_ERR_SHAPE, "channel_sum: npix=%ld C=%d unsupported", npix, C);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = stream_blocks(npix, C / 4);
@@ -655,7 +664,11 @@ extern "C" int ngan_channel_sum(const float* g, float* out, float* workspace, lo
 #undef CALL
     int st = ngan::launch_status("ngan_channel_sum");
     if (st) return st;
-    return ngan::reduce_partials(workspace, nblk, C, out, scale, s);
+    return ngan::reduce_partials_acc(workspace, nblk, C, C, out, C, nullptr, scale, accumulate ? 1 : 0, s);
+}
+
+extern "C" int ngan_channel_sum(const float* g, float* out, float* workspace, long npix, int C, float scale, void* stream) {
+    return ngan_channel_sum_acc(g, out, workspace, npix, C, scale, 0, stream);
 }
 
 extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int Ncol,
@@ -690,11 +703,22 @@ extern "C" int ngan_from_image_dx(const float* g, const float* w, float* gx, int
     return ngan::launch_status("ngan_from_image_dx");
 }
 
+extern "C" int ngan_from_image_dw_acc(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
+                                      int Ncol, int C, int pool, int accumulate, void* stream);
+
 extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
                                   int Ncol, int C, int pool, void* stream) {
+    return ngan_from_image_dw_acc(x, g, gw, gb, workspace, B, H, W, Ncol, C, pool, 0, stream);
+}
+
+// accumulate: bit 0 gw += , bit 1 gb +=
+extern "C" int ngan_from_image_dw_acc(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
+                                      int Ncol, int C, int pool, int accumulate, void* stream) {
     NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "from_image_dw: null pointer");
-    if (B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && !pow2_quads(C))
+    if (B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && !pow2_quads(C)) {
+        NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "from_image_dw: accumulate is not available for C=%d", C);
         return ngan::wide_from_image_dw(x, g, gw, gb, B, H, W, Ncol, C, pool, (hipStream_t)stream);                             // wide.hip
+    }
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
                  "from_image_dw: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
     NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_dw: B*H*W*C/4 must be below 2^31");
@@ -711,8 +735,8 @@ extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, flo
     int st = ngan::launch_status("ngan_from_image_dw");
     if (st) return st;
     const long stride = (long)C * (Ncol + 1);
-    if (!gb) return ngan::reduce_partials_strided(workspace, nblk, C * Ncol, stride, gw, 1.0f, s);
-    return ngan::reduce_partials_split(workspace, nblk, C * (Ncol + 1), stride, gw, C * Ncol, gb, 1.0f, s);   // weight and bias sums: one launch
+    if (!gb) return ngan::reduce_partials_acc(workspace, nblk, C * Ncol, stride, gw, C * Ncol, nullptr, 1.0f, accumulate & 1, s);
+    return ngan::reduce_partials_acc(workspace, nblk, C * (Ncol + 1), stride, gw, C * Ncol, gb, 1.0f, accumulate, s);   // weight and bias sums: one launch
 }
 
 extern "C" int ngan_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, void* stream) {
@@ -730,24 +754,33 @@ extern "C" int ngan_to_image_fwd(const float* x, const float* w, float* t, long 
 }
 
 static int to_image_bwd_impl(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
-                             float* workspace, long npix, int C, int Ncol, const float* rn, float slope, void* stream);
+                             float* workspace, long npix, int C, int Ncol, const float* rn, float slope, int accumulate, void* stream);
 
 extern "C" int ngan_to_image_bwd(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
                                  float* workspace, long npix, int C, int Ncol, void* stream) {
-    return to_image_bwd_impl(g, t, x, w, gx, gw, workspace, npix, C, Ncol, nullptr, 0.f, stream);
+    return to_image_bwd_impl(g, t, x, w, gx, gw, workspace, npix, C, Ncol, nullptr, 0.f, 0, stream);
 }
 
 extern "C" int ngan_to_image_bwd_pnbwd(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
                                        float* gw, float* workspace, long npix, int C, int Ncol, float slope, void* stream) {
     NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
-    return to_image_bwd_impl(g, t, y, w, gc, gw, workspace, npix, C, Ncol, rnorm, slope, stream);
+    return to_image_bwd_impl(g, t, y, w, gc, gw, workspace, npix, C, Ncol, rnorm, slope, 0, stream);
+}
+
+// the same with gw += (accumulate != 0): the colour weights' gradient added straight into an existing gradient buffer
+extern "C" int ngan_to_image_bwd_pnbwd_acc(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
+                                           float* gw, float* workspace, long npix, int C, int Ncol, float slope, int accumulate, void* stream) {
+    NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
+    return to_image_bwd_impl(g, t, y, w, gc, gw, workspace, npix, C, Ncol, rnorm, slope, accumulate, stream);
 }
 
 static int to_image_bwd_impl(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
-                             float* workspace, long npix, int C, int Ncol, const float* rn, float slope, void* stream) {
+                             float* workspace, long npix, int C, int Ncol, const float* rn, float slope, int accumulate, void* stream) {
     NGAN_REQUIRE(g && t && x && w && gx && gw && workspace, NGAN_ERR_ARG, "to_image_bwd: null pointer");
-    if (npix > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0 && !pow2_quads(C))
+    if (npix > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0 && !pow2_quads(C)) {
+        NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "to_image_bwd: accumulate is not available for C=%d", C);
         return ngan::wide_to_image_bwd(g, t, x, w, gx, gw, npix, C, Ncol, rn, slope, (hipStream_t)stream);                       // wide.hip
+    }
     NGAN_REQUIRE(npix > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE, "to_image_bwd: npix=%ld C=%d Ncol=%d unsupported",
                  npix, C, Ncol);
     hipStream_t s = (hipStream_t)stream;
@@ -757,7 +790,7 @@ static int to_image_bwd_impl(const float* g, const float* t, const float* x, con
 #undef CALL
     int st = ngan::launch_status("ngan_to_image_bwd");
     if (st) return st;
-    return ngan::reduce_partials(workspace, nblk, C * Ncol, gw, 1.0f, s);
+    return ngan::reduce_partials_acc(workspace, nblk, C * Ncol, C * Ncol, gw, C * Ncol, nullptr, 1.0f, accumulate ? 1 : 0, s);
 }
 
 #define RESAMPLE_API(NAME, KERNEL, TOTAL)                                                                      \

@@ -468,11 +468,25 @@ def _accumulates_in_place(weight):
         and weight.grad.dtype == torch.float32
 
 
-def _channel_sum(g):
+# Small parameter gradients (biases, FromImage / ToImage / head weights) are added into the parameter's existing .grad buffer by the
+# kernel that computes them -- like the conv weight gradients -- instead of being handed to autograd, whose AccumulateGrad adds each
+# with an elementwise launch of its own (13 such launches per iteration in the round-3 kernel trace)
+_small_grads_in_place = _diag_env("NGAN_SMALL_GRADS_IN_PLACE", "1") != "0"
+
+
+def _channel_sum(g, into=None):
     c = g.shape[-1]
     npix = g.numel() // c
-    out = torch.empty(c, device=g.device, dtype=torch.float32)
+    out = into if into is not None else torch.empty(c, device=g.device, dtype=torch.float32)
     ws = torch.empty(1024 * c, device=g.device, dtype=torch.float32)
+    if into is not None and (c // 4) & (c // 4 - 1) == 0 and c <= 256:
+        _C.call("ngan_channel_sum_acc", g, out, ws, npix, c, 1.0, 1)
+        return out
+    if into is not None:
+        tmp = torch.empty(c, device=g.device, dtype=torch.float32)
+        _C.call("ngan_channel_sum", g, tmp, ws, npix, c, 1.0)
+        into.add_(tmp)
+        return into
     _C.call("ngan_channel_sum", g, out, ws, npix, c, 1.0)
     return out
 
@@ -497,7 +511,13 @@ def _conv_backward_tail(ctx, x, weight, gc, resample, scale, in_link, has_bias, 
             _run_wgrad(x, _c(gc), resample, scale, accumulate_into=weight.grad, pooled=pooled)   # weight.grad += ..., returns None to autograd
         else:
             gw = ConvWgrad.apply(x, gc, resample, scale)
-    gb = ChannelSum.apply(gc) if (has_bias and ctx.needs_input_grad[bias_index] and _param_grads_wanted()) else None
+    gb = None
+    if has_bias and ctx.needs_input_grad[bias_index] and _param_grads_wanted():
+        bias = getattr(ctx, "bias_param", None)
+        if bias is not None and _accumulates_in_place(bias) and _small_grads_in_place:
+            _channel_sum(_c(gc), into=bias.grad)          # bias.grad += ...: no gradient tensor for autograd to add with an elementwise launch
+        else:
+            gb = ChannelSum.apply(gc)
     return gx, gw, gb
 
 
@@ -514,6 +534,7 @@ class ConvLReLUPN(Function):
         ctx.save_for_backward(x, weight, y, rn)
         ctx.pooled = kept[0] if kept else None        # (an intermediate of this node, not an input: held outside saved_tensors)
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None
         ctx.cfg = (resample, scale, slope)
         ctx.n_in = 6 + (3 if pool_out else (in_link is not None or out_link is not None) * 2)
         if in_link is not None and (in_link.y.data_ptr() != x.data_ptr() or in_link.y.shape != x.shape):
@@ -571,6 +592,7 @@ class ConvLReLUPNToImage(Function):
         if keep:
             ctx.save_for_backward(x, weight, y, rn, t, w_img)
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None
         ctx.cfg = (resample, scale, slope)
         if in_link is not None and (in_link.y.data_ptr() != x.data_ptr() or in_link.y.shape != x.shape):
             raise RuntimeError("PixelNorm hand-off: the conv's input is not the linked producer's output")
@@ -584,10 +606,14 @@ class ConvLReLUPNToImage(Function):
         resample, scale, slope = ctx.cfg
         c = y.shape[-1]
         npix = y.numel() // c
-        gw_img = torch.empty_like(w_img)
         ws = torch.empty(1024 * c, device=y.device, dtype=torch.float32)
         gc = torch.empty_like(y)      # ToImage backward and the LeakyReLU->PixelNorm backward in one pass over y
-        _C.call("ngan_to_image_bwd_pnbwd", _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, gw_img, ws, npix, c, 1, float(slope))
+        if _small_grads_in_place and _accumulates_in_place(w_img) and (c // 4) & (c // 4 - 1) == 0 and c <= 256:
+            _C.call("ngan_to_image_bwd_pnbwd_acc", _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, w_img.grad, ws, npix, c, 1, float(slope), 1)
+            gw_img = None             # w_img.grad += ... inside the reduction
+        else:
+            gw_img = torch.empty_like(w_img)
+            _C.call("ngan_to_image_bwd_pnbwd", _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, gw_img, ws, npix, c, 1, float(slope))
         gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
         return gx, gw, gb, gw_img, None, None, None, None, None
 
@@ -780,6 +806,7 @@ class FromImage(Function):
         ctx.save_for_backward(x, w)
         ctx.pool = pool
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None
         return y
 
     @staticmethod
@@ -788,9 +815,18 @@ class FromImage(Function):
         gx = FromImageDx.apply(g, w, ctx.pool) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and _param_grads_wanted():
-            gw, gb = FromImageDw.apply(x, g, ctx.pool, tuple(w.shape))
-            if not ctx.has_bias:
-                gb = None
+            bias = ctx.bias_param
+            c, ncol = w.shape[0], w.shape[1]
+            if (_small_grads_in_place and ctx.needs_input_grad[1] and _accumulates_in_place(w) and (c // 4) & (c // 4 - 1) == 0 and c <= 256
+                    and (not ctx.has_bias or (bias is not None and _accumulates_in_place(bias)))):
+                gg = _c(g)
+                b, h, wd, _ = gg.shape
+                ws = torch.empty(1024 * c * (ncol + 1), device=gg.device, dtype=torch.float32)
+                _C.call("ngan_from_image_dw_acc", x, gg, w.grad, bias.grad if ctx.has_bias else None, ws, b, h, wd, ncol, c, int(ctx.pool), 3)
+            else:
+                gw, gb = FromImageDw.apply(x, g, ctx.pool, tuple(w.shape))
+                if not ctx.has_bias:
+                    gb = None
         return gx, gw, gb, None
 
 
@@ -821,6 +857,7 @@ class FirstBlock(Function):
         _C.call("ngan_first_block_fwd", p, weight.detach(), w_from.detach().reshape(c), b_from, bias, y, rn, tables, b, h, wd, c, n,
                 float(scale), float(slope), PIXELNORM_EPS)
         ctx.save_for_backward(p, w_from, b_from, weight, y, rn, tables)
+        ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None
         ctx.cfg = (pool, scale, slope, bias is not None)
         ctx.out_link = out_link
         if out_link is not None:
@@ -847,11 +884,23 @@ class FirstBlock(Function):
             ws = torch.empty(_C.lib().ngan_first_block_workspace_floats(b, h, n), device=dev, dtype=torch.float32)
             in_place = ctx.needs_input_grad[3] and _accumulates_in_place(weight)
             gw = weight.grad if in_place else torch.empty_like(weight)
-            gwf = torch.empty_like(w_from)
-            gbf = torch.empty_like(b_from) if b_from is not None else None
-            gb = torch.empty(n, device=dev, dtype=torch.float32) if has_bias else None
+            # the three small gradients likewise (accumulate bit mask of ngan_first_block_bwd: 1 conv weight, 2 / 4 FromImage weight / bias, 8 conv bias)
+            bias = ctx.bias_param
+            ip_wf = _small_grads_in_place and ctx.needs_input_grad[1] and _accumulates_in_place(w_from)
+            ip_bf = _small_grads_in_place and b_from is not None and ctx.needs_input_grad[2] and _accumulates_in_place(b_from)
+            ip_b = _small_grads_in_place and has_bias and bias is not None and ctx.needs_input_grad[4] and _accumulates_in_place(bias)
+            gwf = w_from.grad.view(w_from.shape) if ip_wf else torch.empty_like(w_from)
+            gbf = (b_from.grad if ip_bf else torch.empty_like(b_from)) if b_from is not None else None
+            gb = (bias.grad if ip_b else torch.empty(n, device=dev, dtype=torch.float32)) if has_bias else None
+            mask = (1 if in_place else 0) | (2 if ip_wf else 0) | (4 if ip_bf else 0) | (8 if ip_b else 0)
             _C.call("ngan_first_block_bwd", p, gc, weight.detach(), w_from.detach().reshape(c), b_from, gw, gwf, gbf, gb, ws,
-                    b, h, wd, c, n, float(scale), 1 if in_place else 0)
+                    b, h, wd, c, n, float(scale), mask)
+            if ip_wf:
+                gwf = None
+            if ip_bf:
+                gbf = None
+            if ip_b:
+                gb = None
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty((b, 2 * h, 2 * wd, 1) if pool else (b, h, wd, 1), device=dev, dtype=torch.float32)
@@ -875,7 +924,16 @@ class FromImageDx(Function):
     def backward(ctx, h):
         g, w = ctx.saved_tensors
         gg = FromImage.apply(h, w, None, ctx.pool) if ctx.needs_input_grad[0] else None
-        gw = FromImageDw.apply(h, g, ctx.pool, tuple(w.shape))[0] if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            c, ncol = w.shape[0], w.shape[1]
+            if _small_grads_in_place and _accumulates_in_place(w) and (c // 4) & (c // 4 - 1) == 0 and c <= 256:
+                hh = _c(h)
+                b, hgt, wd, _ = g.shape
+                ws = torch.empty(1024 * c * (ncol + 1), device=g.device, dtype=torch.float32)
+                _C.call("ngan_from_image_dw_acc", hh, g, w.grad, None, ws, b, hgt, wd, ncol, c, int(ctx.pool), 1)
+            else:
+                gw = FromImageDw.apply(h, g, ctx.pool, tuple(w.shape))[0]
         return gg, gw, None
 
 
@@ -1102,6 +1160,7 @@ class FinalDot(Function):
         ctx.save_for_backward(y, weight)
         ctx.scale = scale
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias if isinstance(bias, torch.nn.Parameter) else None
         return out
 
     @staticmethod
@@ -1110,9 +1169,15 @@ class FinalDot(Function):
         gy = FinalDotDx.apply(go, weight, ctx.scale, tuple(y.shape)) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and _param_grads_wanted():
-            gw, gb = FinalDotDw.apply(y, go, ctx.scale, tuple(weight.shape))
-            if not ctx.has_bias:
-                gb = None
+            bias = ctx.bias_param
+            if (_small_grads_in_place and ctx.needs_input_grad[1] and _accumulates_in_place(weight)
+                    and (not ctx.has_bias or (bias is not None and _accumulates_in_place(bias)))):
+                b, hh, ww, c = y.shape
+                _C.call("ngan_final_dot_dw_acc", y, _c(go), weight.grad, bias.grad if ctx.has_bias else None, b, hh * ww, c, float(ctx.scale), 3)
+            else:
+                gw, gb = FinalDotDw.apply(y, go, ctx.scale, tuple(weight.shape))
+                if not ctx.has_bias:
+                    gb = None
         return gy, gw, gb, None
 
 
@@ -1131,7 +1196,14 @@ class FinalDotDx(Function):
     def backward(ctx, h):
         go, weight = ctx.saved_tensors
         ggo = FinalDot.apply(h, weight, None, ctx.scale) if ctx.needs_input_grad[0] else None
-        gw = FinalDotDw.apply(h, go, ctx.scale, tuple(weight.shape))[0] if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            if _small_grads_in_place and _accumulates_in_place(weight):
+                hh = _c(h)
+                b, hgt, wd, c = hh.shape
+                _C.call("ngan_final_dot_dw_acc", hh, go, weight.grad, None, b, hgt * wd, c, float(ctx.scale), 1)
+            else:
+                gw = FinalDotDw.apply(h, go, ctx.scale, tuple(weight.shape))[0]
         return ggo, gw, None, None
 
 

@@ -209,6 +209,35 @@ def test_wide_nets_through_the_step_driver(ngan):
         assert torch.equal(p, pe), f"{name}: {float((p - pe).abs().max())}"
 
 
+def test_small_gradients_added_in_place_equal_autograds_accumulation(ngan, monkeypatch):
+    """Biases and the FromImage / ToImage / head weights get their gradients added into .grad by the kernel that computes them
+    (ngan_*_acc, ops._small_grads_in_place) instead of by autograd's AccumulateGrad.  Same contributions, same order, one fp32 add
+    each: the trajectory must equal the one with the switch off bit for bit (fading stage, so the faded-in branches accumulate too)."""
+    def make():
+        torch.manual_seed(31)
+        G = ngan.models.Generator_PG([32, 16, 16], image_size_init=8, latent_dim=32)
+        D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=8)
+        G.set_resolution(32, 0.4)
+        D.set_resolution(32, 0.4)
+        return ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), learning_rate=1e-3)
+    gen = torch.Generator().manual_seed(9)
+    def draw(b):
+        z = [torch.randn(b, 32, generator=gen) for _ in range(3)]
+        z = [(v / v.norm(dim=1, keepdim=True)).to(DEV) for v in z]
+        return ((torch.rand(b, 1, 32, 32, generator=gen) * 2 - 1).to(DEV), z[0], z[1], torch.rand(b, 1, 1, 1, generator=gen).to(DEV), z[2])
+    seq = [draw(8) for _ in range(3)]
+    assert ngan.ops._small_grads_in_place
+    a, b = make(), make()
+    for s in seq:
+        a.train_iteration(*s)
+    monkeypatch.setattr(ngan.ops, "_small_grads_in_place", False)
+    for s in seq:
+        b.train_iteration(*s)
+    torch.cuda.synchronize()
+    for name, p, pe in zip(a.flat_g.names + a.flat_d.names, a.flat_g.params + a.flat_d.params, b.flat_g.params + b.flat_d.params):
+        assert torch.equal(p, pe), f"{name}: {float((p - pe).abs().max())}"
+
+
 def test_penalty_switched_off_draws_no_second_latent_batch(ngan):
     """grad_pen_lambda = 0 is the reference CLI's argparse default: D_grad_pen_loss returns 0 (loss_functions.py:179) and draws
     nothing.  The step driver must run (round 1 stacked a CPU scalar with device tensors) and must not generate the unused fakes."""
