@@ -13,7 +13,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------
 // Tile schedule of the persistent kernels: as many workgroups as are resident, an equal share of tiles each, strided inside the
 // band of the workgroup's XCD (blockIdx & 7), so that neighbouring tiles meet in one L2 at about the same time.
-// Measured and rejected (tools/clock_probe.py, fp32 16 -> 16 at 512x512, 177 us): the workgroups of a CU finish up to 75 us apart
+// Measured and rejected (round 2's in-kernel clock probe, fp32 16 -> 16 at 512x512, 177 us): the workgroups of a CU finish up to 75 us apart
 // (the waves sharing a SIMD are served oldest first), but neither an atomic ticket queue (220 us: the compiler guards the tile
 // loop's register hazards with s_waitcnt vmcnt(0..1), so every tile waited for the in-flight atomic) nor an over-decomposed grid
 // that the dispatcher back-fills (2 / 4 / 8 tiles per workgroup: 184 / 181 / 180 us) is faster: the tail is not where the time goes.

@@ -4,7 +4,7 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------------------
 // conv3x3_tile_kernel: the persistent kernel for plain (not resampled) input on images whose width is a multiple of the 32-pixel
-// tile, rebuilt around one measurement (tools/clock_probe.py + the NGAN_EXP builds): v_mfma_f32_16x16x4_f32 runs on the vector
+// tile, rebuilt around one measurement (round 2's in-kernel clock probe and one-phase-compiled-out builds, profiles/r02_clock_probe_and_phase_experiments.txt): v_mfma_f32_16x16x4_f32 runs on the vector
 // FMA lanes, so every VALU instruction any wave of the SIMD issues is 4 cycles the matrix instructions do not get -- the fp32
 // 16 -> 16 layer spent 190 VALU instructions per 144 MFMAs of a wave's tile, 80 of them integer address / bounds arithmetic.
 // Here the per-tile arithmetic is scalar:
