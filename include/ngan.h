@@ -244,6 +244,12 @@ int ngan_linear_wgrad(const float* z, const float* gc, float* gW, int B, int K, 
 /* accumulate != 0: gW += ... (K <= 512, a multiple of 16): adds straight into the parameter's gradient buffer */
 int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale, int accumulate,
                           void* stream);
+/* the same contraction with Adam applied in its epilogue instead of a stored gradient (K <= 512, a multiple of 16; any B -- the
+ * data-parallel ranks pass the gathered factors): p, m, v are the stem weight's slices of the flat parameter / moment buffers,
+ * seg_step points at its (already advanced) step count, hyper as in ngan_adam_step.  Replaces, for this tensor, the store in
+ * ngan_linear_wgrad plus its chunks of ngan_adam_step: same arithmetic, same bits. */
+int ngan_linear_wgrad_adam(const float* z, const float* gc, float* p, float* m, float* v, const float* seg_step,
+                           const float* hyper, int B, int K, int S, int C, float scale, void* stream);
 int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream);
 
 /* ---- critic head: Conv2d_normalized(C, 1, (S,S), padding 0) + Flatten, models.py:485-490 ------------------------

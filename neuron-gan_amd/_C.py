@@ -53,6 +53,7 @@ SIGNATURES = {
     "ngan_linear_lrelu_pn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P],
     "ngan_linear_wgrad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ngan_linear_wgrad_acc": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "ngan_linear_wgrad_adam": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ngan_linear_dgrad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ngan_final_dot_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "ngan_final_dot_dx": [_P, _P, _P, _I, _I, _I, _F, _P],

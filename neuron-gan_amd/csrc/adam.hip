@@ -22,21 +22,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    const long* __restrict__ chunk_off, const float* __restrict__ hyper) {
     const int seg = chunk_seg[blockIdx.x];
     if (!seg_active[seg]) return;
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gscale = hyper[4];
-    const float t = seg_step[seg];
-    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    const AdamCoef k = adam_coef(hyper, seg_step[seg]);
     const long off = chunk_off[blockIdx.x];
     const long base = seg_off[seg] + off;
     const long n = min((long)CHUNK, seg_len[seg] - off);
     for (long i = threadIdx.x; i < n; i += 256) {
         const long j = base + i;
-        const float gv = g[j] * gscale;   // 1/world_size after a SUM all-reduce, else 1
-        const float mv = fmaf(1.0f - b1, gv - m[j], m[j]);            // m.lerp_(g, 1 - beta1)
-        const float vv = fmaf(b2, v[j], (1.0f - b2) * gv * gv);      // v.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        float pv = p[j], mv = m[j], vv = v[j];
+        adam_update(k, g[j], pv, mv, vv);
         m[j] = mv;
         v[j] = vv;
-        p[j] -= step_size * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));  // p.addcdiv_(m, sqrt(v)/sqrt(bc2) + eps, -lr/bc1)
+        p[j] = pv;
     }
 }
 

@@ -791,7 +791,9 @@ __host__ __device__ inline int reduce_groups(const ReduceEntry& e) {
     return np >= 128 ? 16 : np >= 64 ? 8 : np >= 32 ? 4 : np >= 16 ? 2 : 1;
 }
 __global__ __launch_bounds__(kReduceThreads) void wgrad_reduce_many_kernel(ReduceBatch b) {
-    __shared__ float red[kReduceThreads];
+    // a thread owns FOUR consecutive elements (one 16-byte load per slab: a wave reads 1 KB runs, four times the bytes in flight of
+    // the dword version, which ran at 2.4 TB/s); a slab is 9 * co_s * ci_s floats, a multiple of 4, so a quad never straddles M
+    __shared__ float4 red[kReduceThreads];
     int ei = 0;
     for (int i = 1; i < b.n; ++i)
         if ((int)blockIdx.x >= b.e[i].first_block) ei = i;
@@ -800,44 +802,49 @@ __global__ __launch_bounds__(kReduceThreads) void wgrad_reduce_many_kernel(Reduc
     const long M = (long)e.nslices * slab;
     const int NG = reduce_groups(e), span = kReduceThreads / NG;
     const int tid = threadIdx.x, el = tid & (span - 1), grp = tid / span;
-    const long i = (long)(blockIdx.x - e.first_block) * span + el;
-    float total = 0.f;
+    const long i = ((long)(blockIdx.x - e.first_block) * span + el) * 4;
+    float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < e.nsrc; ++s) {
-        float acc = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < M) {
             // eight independent partial sums: the slab reads of one thread are in flight together instead of one per round trip
             const float* src = e.partial[s] + i;
             const int np = e.nparts[s];
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+            float4 a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             int j = grp;
             for (; j + 7 * NG < np; j += 8 * NG) {
-                a0 += src[(long)j * M]; a1 += src[(long)(j + NG) * M];
-                a2 += src[(long)(j + 2 * NG) * M]; a3 += src[(long)(j + 3 * NG) * M];
-                a4 += src[(long)(j + 4 * NG) * M]; a5 += src[(long)(j + 5 * NG) * M];
-                a6 += src[(long)(j + 6 * NG) * M]; a7 += src[(long)(j + 7 * NG) * M];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = f4add(a[k], ld4(src + (long)(j + k * NG) * M));
             }
-            for (; j < np; j += NG) a0 += src[(long)j * M];
-            a0 += a4; a1 += a5; a2 += a6; a3 += a7;
-            acc = (a0 + a1) + (a2 + a3);
+            for (; j < np; j += NG) a[0] = f4add(a[0], ld4(src + (long)j * M));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = f4add(a[k], a[k + 4]);
+            acc = f4add(f4add(a[0], a[1]), f4add(a[2], a[3]));
         }
         __syncthreads();
         red[tid] = acc;
         __syncthreads();
         if (tid < span) {
-            float t = 0.f;
-            for (int j = 0; j < NG; ++j) t += red[tid + span * j];
-            total = fmaf(t, e.scale[s], total);
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < NG; ++j) t = f4add(t, red[tid + span * j]);
+            total = f4fma(t, e.scale[s], total);
         }
     }
     if (tid < span && i < M) {
-        int r = (int)(i % slab);
-        const int slice = (int)(i / slab);
-        const int ci_l = r % e.ci_s; r /= e.ci_s;
-        const int co_l = r % e.co_s;
-        const int tap = r / e.co_s;
-        const int co = (slice / e.n_ci_slices) * e.co_s + co_l, ci = (slice % e.n_ci_slices) * e.ci_s + ci_l;
-        float* o = e.gw + ((long)co * e.K + ci) * 9 + tap;
-        *o = e.accumulate ? *o + total : total;
+        const float tv[4] = {total.x, total.y, total.z, total.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int r = (int)((i + k) % slab);
+            const int slice = (int)((i + k) / slab);
+            const int ci_l = r % e.ci_s; r /= e.ci_s;
+            const int co_l = r % e.co_s;
+            const int tap = r / e.co_s;
+            const int co = (slice / e.n_ci_slices) * e.co_s + co_l, ci = (slice % e.n_ci_slices) * e.ci_s + ci_l;
+            float* o = e.gw + ((long)co * e.K + ci) * 9 + tap;
+            *o = e.accumulate ? *o + tv[k] : tv[k];
+        }
     }
 }
 
@@ -868,7 +875,7 @@ extern "C" int ngan_conv3x3_wgrad_reduce_many(const void* entries, int n, void* 
             b.e[i] = src[base + i];
             NGAN_REQUIRE(b.e[i].nsrc >= 1 && b.e[i].nsrc <= 4 && b.e[i].gw, NGAN_ERR_ARG, "conv3x3_wgrad_reduce_many: bad entry %d", base + i);
             b.e[i].first_block = blocks;
-            blocks += ngan::ceil_div((long)b.e[i].nslices * 9 * b.e[i].co_s * b.e[i].ci_s, kReduceThreads / reduce_groups(b.e[i]));
+            blocks += ngan::ceil_div((long)b.e[i].nslices * 9 * b.e[i].co_s * b.e[i].ci_s, 4 * (kReduceThreads / reduce_groups(b.e[i])));
         }
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(blocks), dim3(kReduceThreads), 0, (hipStream_t)stream, b);
         int st = ngan::launch_status("ngan_conv3x3_wgrad_reduce_many");

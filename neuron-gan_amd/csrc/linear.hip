@@ -134,10 +134,14 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 // stem exchange forms the full-batch gradient from world*B gathered samples): a wave owns 16 weight rows and all K columns,
 // A = z^T (16 k-columns x 4 samples), B = gc (4 samples x 16 rows), so a lane ends with 4 consecutive k of one row: one
 // 16-byte store.  z (B x K) and gc are tiny and stay in L1/L2; the 4*C*S*K-byte result is written exactly once.
-template <int NT>
+// ADAM: the gradient is never stored -- the lane applies Adam to its 4 * NT elements of the parameter and its moments (p, m, v are
+// the tensor's slices of the flat buffers; step / hyper as in ngan_adam_step).  The stem holds 16.8 M of the generator's 17.1 M
+// parameters: the stored form costs a 67 MB zero fill, a 67 MB read-modify-write here and a 67 MB read in the Adam kernel.
+struct StemAdam { float* p; float* m; float* v; const float* hyper; const float* step; };
+template <int NT, bool ADAM = false>
 __global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __restrict__ z, const float* __restrict__ gc,
                                                                 float* __restrict__ gW, int B, int K, int S, int C, float scale,
-                                                                int accumulate) {
+                                                                int accumulate, StemAdam ad = StemAdam{}) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const long rows = (long)C * S;
@@ -159,6 +163,25 @@ __global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __r
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[t], gv, acc[t], 0, 0, 0);
+    }
+    if (ADAM) {
+        if (rok) {
+            const AdamCoef k = adam_coef(ad.hyper, ad.step[0]);
+            const long o = row * K + kq * 4;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t < nt) {
+                    float4 pv = ld4(ad.p + o + t * 16), mv = ld4(ad.m + o + t * 16), vv = ld4(ad.v + o + t * 16);
+                    adam_update(k, acc[t][0] * scale, pv.x, mv.x, vv.x);
+                    adam_update(k, acc[t][1] * scale, pv.y, mv.y, vv.y);
+                    adam_update(k, acc[t][2] * scale, pv.z, mv.z, vv.z);
+                    adam_update(k, acc[t][3] * scale, pv.w, mv.w, vv.w);
+                    st4(ad.m + o + t * 16, mv);
+                    st4(ad.v + o + t * 16, vv);
+                    st4(ad.p + o + t * 16, pv);
+                }
+        }
+        return;
     }
     if (rok) {
         float* o = gW + row * K + kq * 4;
@@ -302,14 +325,26 @@ extern "C" int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW,
     const long rows = (long)C * S;
     if (K % 16 == 0 && K <= 512) {
         const dim3 grid(ngan::ceil_div(rows, 64)), block(256);
-        if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<8>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate);
-        else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<32>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate);
+        if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<8, false>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate, StemAdam{});
+        else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<32, false>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate, StemAdam{});
         return ngan::launch_status("ngan_linear_wgrad(mfma)");
     }
     const int rpb = rows >= 4096 ? 16 : 4;
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3(ngan::ceil_div(rows, rpb)), dim3(256), 0, (hipStream_t)stream, z, gc, gW,
                        B, K, S, C, scale, rpb);
     return ngan::launch_status("ngan_linear_wgrad");
+}
+
+extern "C" int ngan_linear_wgrad_adam(const float* z, const float* gc, float* p, float* m, float* v, const float* seg_step,
+                                      const float* hyper, int B, int K, int S, int C, float scale, void* stream) {
+    NGAN_REQUIRE(z && gc && p && m && v && seg_step && hyper, NGAN_ERR_ARG, "linear_wgrad_adam: null pointer");
+    NGAN_REQUIRE(B > 0 && S > 0 && C > 0 && K > 0 && K % 16 == 0 && K <= 512, NGAN_ERR_SHAPE,
+                 "linear_wgrad_adam: B=%d K=%d S=%d C=%d unsupported (K a multiple of 16, at most 512)", B, K, S, C);
+    const dim3 grid(ngan::ceil_div((long)C * S, 64)), block(256);
+    const StemAdam ad{p, m, v, hyper, seg_step};
+    if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<8, true>), grid, block, 0, (hipStream_t)stream, z, gc, nullptr, B, K, S, C, scale, 0, ad);
+    else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<32, true>), grid, block, 0, (hipStream_t)stream, z, gc, nullptr, B, K, S, C, scale, 0, ad);
+    return ngan::launch_status("ngan_linear_wgrad_adam");
 }
 
 extern "C" int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream) {

@@ -56,6 +56,23 @@ int wide_from_image_dw(const float* x, const float* g, float* gw, float* gb, int
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// One element of optim.Adam.step (train.py:224-225: betas (beta1, 0.999), eps 1e-8, no weight decay, no amsgrad) -- shared by the flat
+// multi-tensor kernel (adam.hip) and the generator stem's gradient-free update (linear.hip), so both produce the same bits.
+struct AdamCoef { float b1, b2, eps, gscale, step_size, inv_sqrt_bc2; };
+__device__ __forceinline__ AdamCoef adam_coef(const float* __restrict__ hyper, float t) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2];
+    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    return AdamCoef{b1, b2, hyper[3], hyper[4], lr / bc1, 1.0f / sqrtf(bc2)};
+}
+__device__ __forceinline__ void adam_update(const AdamCoef& k, float g, float& p, float& m, float& v) {
+    const float gv = g * k.gscale;                                 // 1/world_size after a SUM exchange, else 1
+    const float mv = fmaf(1.0f - k.b1, gv - m, m);                 // m.lerp_(g, 1 - beta1)
+    const float vv = fmaf(k.b2, v, (1.0f - k.b2) * gv * gv);      // v.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    m = mv;
+    v = vv;
+    p -= k.step_size * (mv / (sqrtf(vv) * k.inv_sqrt_bc2 + k.eps));   // p.addcdiv_(m, sqrt(v)/sqrt(bc2) + eps, -lr/bc1)
+}
+
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4fma(float4 a, float s, float4 c) {

@@ -104,12 +104,25 @@ class FusedAdam:
         self.hyper_host[0] = float(self.param_groups[0]["lr"])
         self.hyper.copy_(torch.tensor(self.hyper_host, dtype=torch.float32), non_blocking=True)
 
-    def step(self):
+    def step(self, stem_factors=None):
+        """stem_factors: (z, gc, s2, c, scale) of the generator stem (tensor 0 of the flat buffer) when its gradient was NOT stored
+        (PGGANTrainer.fused_stem): its chunks are left out of the flat launch and `ngan_linear_wgrad_adam` forms the gradient from
+        the factors and applies the same update in its epilogue."""
         f = self.flat
         if self.hyper_host[0] != self.param_groups[0]["lr"]:
             self._push()
+        n0 = 0
+        if stem_factors is not None:
+            assert f.active_host[0] == 1, "the stem is active at every stage"
+            n0 = (f.params[0].numel() + ADAM_CHUNK - 1) // ADAM_CHUNK
+        n_chunks = int(f.chunk_seg.numel()) - n0
         _C.call("ngan_adam_step", f.flat, f.grad, f.exp_avg, f.exp_avg_sq, f.seg_off, f.seg_len, f.seg_active, f.seg_step,
-                len(f.params), f.chunk_seg, f.chunk_off, int(f.chunk_seg.numel()), self.hyper)
+                len(f.params), f.chunk_seg[n0:], f.chunk_off[n0:], n_chunks, self.hyper)      # also advances every active step count
+        if stem_factors is not None:
+            z, gc, s2, c, scale = stem_factors
+            n = f.params[0].numel()
+            _C.call("ngan_linear_wgrad_adam", z, gc, f.flat[:n], f.exp_avg[:n], f.exp_avg_sq[:n], f.seg_step[:1], self.hyper,
+                    z.shape[0], z.shape[1], s2, c, float(scale))
         self.repack()
 
     def repack(self):
@@ -138,6 +151,8 @@ class StemGradExchange:
     def __init__(self, weight, world, group=None, wgrad_fn=None):
         self.weight, self.world, self.group = weight, world, group
         self.captured = None     # kept after finish(): under graph replay the same (static) tensors are refilled every step
+        self.factors = None      # (z, gc, s2, c, scale) over ALL ranks' samples after finish(): what FusedAdam.step(stem_factors=) takes
+        self._gathered = {}      # gather buffers per factor shape: captured Adam launches read them, so they must not move
         self.wgrad_fn = wgrad_fn or (lambda zs, gs, out, n, k, s2, c, scale:
                                      _C.call("ngan_linear_wgrad", zs, gs, out, n, k, s2, c, float(scale)))
 
@@ -145,16 +160,20 @@ class StemGradExchange:
         assert weight is self.weight
         self.captured = (z, gc, s2, c, scale)
 
-    def finish(self, run_collectives=None):
-        """all-gather the factors and write the full-batch gradient into weight.grad (call after backward).  `run_collectives(fn)`
-        executes the collectives (the step driver passes its communication-stream runner, PGGANTrainer._on_comm_stream)."""
+    def finish(self, run_collectives=None, materialize=True):
+        """all-gather the factors and (materialize) write the full-batch gradient into weight.grad (call after backward).
+        `run_collectives(fn)` executes the collectives (the step driver passes its communication-stream runner,
+        PGGANTrainer._on_comm_stream).  With materialize=False the gradient is never formed: `self.factors` goes to the fused Adam."""
         if self.captured is None:
             return
         z, gc, s2, c, scale = self.captured
         b, k = z.shape
         if self.world > 1:
-            zs = torch.empty((self.world * b, k), device=z.device, dtype=z.dtype)
-            gs = torch.empty((self.world * b,) + tuple(gc.shape[1:]), device=gc.device, dtype=gc.dtype)
+            key = (self.world * b, k) + tuple(gc.shape[1:])
+            if key not in self._gathered:
+                self._gathered[key] = (torch.empty((self.world * b, k), device=z.device, dtype=z.dtype),
+                                       torch.empty((self.world * b,) + tuple(gc.shape[1:]), device=gc.device, dtype=gc.dtype))
+            zs, gs = self._gathered[key]
             zc, gcc = z.contiguous(), gc.contiguous()
 
             def gather():
@@ -162,8 +181,10 @@ class StemGradExchange:
                 dist.all_gather_into_tensor(gs, gcc, group=self.group)
             (run_collectives or (lambda fn: fn()))(gather)
         else:
-            zs, gs = z, gc
-        self.wgrad_fn(zs, gs, self.weight.grad, zs.shape[0], k, s2, c, scale)
+            zs, gs = z.contiguous(), gc.contiguous()
+        self.factors = (zs, gs, s2, c, scale)
+        if materialize:
+            self.wgrad_fn(zs, gs, self.weight.grad, zs.shape[0], k, s2, c, scale)
 
 
 def active_parameters(net):
@@ -204,7 +225,7 @@ class PGGANTrainer:
     """One object per process (= per GPU).  `train_iteration(real)` is train.py:356-385 with sim_loss off."""
 
     def __init__(self, generator, discriminator, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001,
-                 n_critic=1, alpha_step=1e-4, process_group=None, device_latents=False):
+                 n_critic=1, alpha_step=1e-4, process_group=None, device_latents=False, fused_stem=None):
         self.G, self.D = generator, discriminator
         self.device = next(generator.parameters()).device
         self.n_critic = n_critic
@@ -219,10 +240,16 @@ class PGGANTrainer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.stem = None
+        self._stem_grad_skipped = self._stem_sink_active = self._stem_for_exchange = False
         if self.world > 1:
             self.opt_g.set_grad_scale(1.0 / self.world)
             self.opt_d.set_grad_scale(1.0 / self.world)
             self.enable_stem_exchange()
+        # The generator stem's weight gradient is not stored when the stem qualifies (GPU, latent_dim a multiple of 16, at most 512):
+        # g_step hands its factors to the Adam launch (FusedAdam.step).  g_compute on its own still stores it.  fused_stem=False: never.
+        self.fused_stem = False
+        if fused_stem or (fused_stem is None and self.device.type == "cuda" and ops._diag_env("NGAN_FUSED_STEM_ADAM", "1") != "0"):
+            self.enable_fused_stem()
         self.force_exchange = False
         self.last_z_g = None
         # collectives of the RCCL backend run on a stream of their own (see _on_comm_stream); created on first need
@@ -235,12 +262,22 @@ class PGGANTrainer:
         self.refresh_stage()
         ops.bump_weight_epoch()
 
-    def enable_stem_exchange(self):
+    def enable_stem_exchange(self, for_exchange=True):
         """Exchange the stem's gradient as gathered factors; the all-reduce then skips its segment of the flat buffer."""
+        self._stem_for_exchange = self._stem_for_exchange or for_exchange
+        if self.stem is not None:
+            return
         first = self.G.layers[0]
         if hasattr(first, "weight") and first.weight.dim() == 2 and self.flat_g.index[id(first.weight)] == 0:
             self.stem = StemGradExchange(first.weight, self.world, self.group)
             self._stem_elems = (first.weight.numel() + SEG_ALIGN - 1) // SEG_ALIGN * SEG_ALIGN
+
+    def enable_fused_stem(self):
+        if self.stem is None:
+            self.enable_stem_exchange(for_exchange=False)
+        k = self.stem.weight.shape[1] if self.stem is not None else 0
+        self.fused_stem = self.stem is not None and k % 16 == 0 and 0 < k <= 512
+        return self.fused_stem
 
     # ---- stage bookkeeping -------------------------------------------------------------------------------
     def refresh_stage(self):
@@ -314,9 +351,9 @@ class PGGANTrainer:
         cur.wait_stream(self._comm_stream)
 
     def _exchange(self, flat):
-        if flat is self.flat_g and self.stem is not None:
+        if flat is self.flat_g and self._stem_sink_active:
             # the stem occupies the head of G's flat buffer: gather its factors, all-reduce only the tail
-            self.stem.finish(lambda fn: self._on_comm_stream(fn, "generator"))
+            self.stem.finish(lambda fn: self._on_comm_stream(fn, "generator"), materialize=not self._stem_grad_skipped)
             if self.world > 1 or self.force_exchange:
                 self._on_comm_stream(lambda: dist.all_reduce(flat.grad[self._stem_elems:], op=dist.ReduceOp.SUM, group=self.group), "generator")
             return
@@ -358,16 +395,23 @@ class PGGANTrainer:
         self.opt_d.step()  # train.py:366
         return stats
 
-    def g_compute(self, real, z=None):
+    def g_compute(self, real, z=None, skip_stem_grad=False):
+        """skip_stem_grad (g_step with fused_stem): the stem's gradient is neither zeroed nor stored -- its factors wait in self.stem"""
         b = real.size(0)
         self.flat_g.ensure_grad_views()
-        self.flat_g.zero_grad()  # Generator_net.zero_grad(), train.py:375
+        self._stem_grad_skipped = bool(skip_stem_grad and self.fused_stem)
+        if self._stem_grad_skipped:
+            self.flat_g.grad[self._stem_elems:].zero_()
+        else:
+            self.flat_g.zero_grad()  # Generator_net.zero_grad(), train.py:375
         d_params = self.flat_d.params
         for p in d_params:  # the reference also back-propagates into the critic's weights here and discards the result
             p.requires_grad_(False)
         try:
             loss, self.last_z_g = self.g_loss(real, z=self._latent(b, z))  # train.py:376
-            ops.linear_grad_sink = self.stem.sink if self.stem is not None else None
+            # the stem hands over factors instead of a gradient when they are exchanged (data parallel) or go straight to Adam
+            self._stem_sink_active = self.stem is not None and (self._stem_for_exchange or self._stem_grad_skipped)
+            ops.linear_grad_sink = self.stem.sink if self._stem_sink_active else None
             try:
                 with ops.deferred_wgrad():
                     loss.backward()  # train.py:384
@@ -378,10 +422,13 @@ class PGGANTrainer:
                 p.requires_grad_(True)
         return {"G_loss": loss.detach()}
 
+    def g_adam(self):
+        self.opt_g.step(self.stem.factors if self._stem_grad_skipped else None)  # train.py:385
+
     def g_step(self, real, z=None):
-        stats = self.g_compute(real, z)
+        stats = self.g_compute(real, z, skip_stem_grad=True)
         self._exchange(self.flat_g)
-        self.opt_g.step()  # train.py:385
+        self.g_adam()
         return stats
 
     def train_iteration(self, real, z_d=None, z_gp=None, eps=None, z_g=None):
@@ -520,10 +567,10 @@ class PGGANTrainer:
             self._exchange(self.flat_d)                  # eager, on the communication stream; its result is discarded below
             with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=mode):
                 self.opt_d.step()
-                stats.update(self.g_compute(static_real, z_g))
+                stats.update(self.g_compute(static_real, z_g, skip_stem_grad=True))
             self._exchange(self.flat_g)
             with torch.cuda.graph(gc, pool=ga.pool(), capture_error_mode=mode):
-                self.opt_g.step()
+                self.g_adam()
             graphs = [ga, gb, gc]
             torch.cuda.synchronize()
             self.flat_d.grad.zero_()                     # the exchanges above summed never-computed gradients: leave nothing behind

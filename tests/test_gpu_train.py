@@ -211,8 +211,10 @@ def test_wide_nets_through_the_step_driver(ngan):
 
 def test_small_gradients_added_in_place_equal_autograds_accumulation(ngan, monkeypatch):
     """Biases and the FromImage / ToImage / head weights get their gradients added into .grad by the kernel that computes them
-    (ngan_*_acc, ops._small_grads_in_place) instead of by autograd's AccumulateGrad.  Same contributions, same order, one fp32 add
-    each: the trajectory must equal the one with the switch off bit for bit (fading stage, so the faded-in branches accumulate too)."""
+    (ngan_*_acc, ops._small_grads_in_place) instead of by autograd's AccumulateGrad.  Same contributions in the same order; the
+    kernels' `grad + scale * sum` is one fused multiply-add where autograd rounds the product first, so the two trajectories agree
+    to the last bits, not bit for bit (measured: 3e-6 on weights of size 0.3 after three Adam steps of 1e-3).  Fading stage, so the
+    faded-in branches accumulate too."""
     def make():
         torch.manual_seed(31)
         G = ngan.models.Generator_PG([32, 16, 16], image_size_init=8, latent_dim=32)
@@ -234,8 +236,14 @@ def test_small_gradients_added_in_place_equal_autograds_accumulation(ngan, monke
     for s in seq:
         b.train_iteration(*s)
     torch.cuda.synchronize()
+    moved = False
     for name, p, pe in zip(a.flat_g.names + a.flat_d.names, a.flat_g.params + a.flat_d.params, b.flat_g.params + b.flat_d.params):
-        assert torch.equal(p, pe), f"{name}: {float((p - pe).abs().max())}"
+        # Adam normalises every element's step to ~lr, so an element whose gradient is ~0 can move by up to lr per step on a last-bit
+        # difference: bound the worst element by a fraction of the 3 * lr the weights moved, and the tensor as a whole tightly
+        assert float((p - pe).abs().max()) < 3e-4, f"{name}: {float((p - pe).abs().max())}"
+        assert float((p - pe).norm()) <= 2e-5 * float(pe.norm()) + 1e-7, f"{name}: {float((p - pe).norm() / pe.norm())}"
+        moved = moved or not torch.equal(p, pe)
+    assert all(float(p.grad.abs().max()) > 0 for p in a.flat_d.params if p.numel() < 64 and a.flat_d.active_host[a.flat_d.index[id(p)]])
 
 
 def test_penalty_switched_off_draws_no_second_latent_batch(ngan):
@@ -290,26 +298,34 @@ def test_epoch_driver_follows_the_reference_epoch_by_epoch(ngan):
 
 def test_stem_factor_exchange_matches_plain_gradient(ngan):
     """The data-parallel path forms the stem's weight gradient from (gathered) factors after the backward pass; with one rank
-    that must give exactly the weights of the plain path."""
+    that must give exactly the weights of the plain path.  So must the default path on the GPU, which hands the factors to Adam and
+    never stores that gradient (PGGANTrainer.fused_stem)."""
     fix = load_golden("small_res8_warm")
     res, alpha, init, latent, batch, _ = fix["meta"]
     out = []
-    for use_stem in (False, True):
+    for mode in ("plain", "factors", "adam_epilogue"):
         G = ngan.models.Generator_PG([32, 16, 16], image_size_init=int(init), latent_dim=int(latent))
         D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=int(init))
         G.set_resolution(int(res), float(alpha))
         D.set_resolution(int(res), float(alpha))
         G.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "G/").items()})
         D.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "D/").items()})
-        tr = ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), learning_rate=1e-3)
-        if use_stem:
+        tr = ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), learning_rate=1e-3, fused_stem=(mode == "adam_epilogue"))
+        if mode == "factors":
             tr.enable_stem_exchange()
             assert tr.stem is not None
+        assert tr.fused_stem == (mode == "adam_epilogue")
         t = lambda k: torch.from_numpy(fix[k]).to(DEV)
-        tr.train_iteration(t("real"), z_d=t("z_d"), z_gp=t("z_gp"), eps=t("eps"), z_g=t("z_g"))
+        for _ in range(3):      # three updates: the per-tensor step count and both moments take part
+            tr.train_iteration(t("real"), z_d=t("z_d"), z_gp=t("z_gp"), eps=t("eps"), z_g=t("z_g"))
+        if mode == "adam_epilogue":
+            # the third form never stores the stem's gradient (ngan_linear_wgrad_adam: Adam in the epilogue of the factor product)
+            assert float(tr.stem.weight.grad.abs().max()) == 0.0
         out.append({k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
+        out[-1]["exp_avg"], out[-1]["exp_avg_sq"] = tr.flat_g.exp_avg.cpu().clone(), tr.flat_g.exp_avg_sq.cpu().clone()
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+        assert torch.equal(out[0][k], out[2][k]), k
 
 
 def test_eager_iterations_do_not_leak_device_memory(ngan):
