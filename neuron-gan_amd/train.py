@@ -422,6 +422,13 @@ class PGGANTrainer:
                 p.requires_grad_(True)
         return {"G_loss": loss.detach()}
 
+    def materialize_stem_grad(self):
+        """After a g_step that skipped the stem's gradient (fused_stem), write it into the stem weight's .grad from that step's
+        factors -- for inspection (gradient norms, the parity tests); the update itself never needs it."""
+        if self._stem_grad_skipped and self.stem is not None and self.stem.factors is not None:
+            zs, gs, s2, c, scale = self.stem.factors
+            self.stem.wgrad_fn(zs, gs, self.stem.weight.grad, zs.shape[0], zs.shape[1], s2, c, scale)
+
     def g_adam(self):
         self.opt_g.step(self.stem.factors if self._stem_grad_skipped else None)  # train.py:385
 

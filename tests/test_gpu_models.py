@@ -44,6 +44,7 @@ def run_step_losses(ngan, G, D, fix, lam=10.0, drift=0.001, lr=1e-4):
     dgrads = {cur_d[id(p)]: p.grad.detach().cpu().numpy().copy() for p, a in zip(fd.params, fd.active_host) if a}
     norms = tr.gp_loss.last_grad_norms.cpu().numpy()
     sg = tr.g_step(t("real"), z=t("z_g"))
+    tr.materialize_stem_grad()      # g_step applies Adam to the stem from the gradient's factors and stores no gradient for it
     fg = tr.flat_g
     ggrads = {cur_g[id(p)]: p.grad.detach().cpu().numpy().copy() for p, a in zip(fg.params, fg.active_host) if a}
     scal = np.array([float(sd["D_loss"]), float(sd["score_real"]), float(sd["score_fake"]), float(sd["D_grad_pen"]),
