@@ -21,7 +21,9 @@ Rank 0 prints ONE JSON line: images/s over all ranks, plus
                   largest summed time, timed with HIP events on its launch stream: exact-fp32 instances against the fp32 MFMA
                   roof (157.3 TFLOP/s: achieved = 2*9*K*N*pixels of its launches / their summed duration), split-bf16 instances
                   against HBM (8 TB/s: achieved = algorithmic bytes / duration); traffic = HBM bytes per launch from the
-                  committed PMC summary (profiles/, tools/measure_round.sh)
+                  PMC counters, collected INSIDE this invocation at N = 1 (two rocprofv3 passes over a child run of this script,
+                  `live_traffic`; `traffic_source` says so) with the committed summary (profiles/, tools/measure_round.sh) as the
+                  fallback when the profiler cannot run
   cpu_baseline -- the CPU oracle (oracle/pggan_oracle.py, a port of the reference's path) timed on this host's cores on a
                   bounded sample of the same workload at the same batch (N = 1 only), with the CPU model string.
 
@@ -226,6 +228,64 @@ def cpu_baseline(res, alpha, batch, budget_s=25.0, max_iters=4):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the dominant kernel, measured in THIS run: two rocprofv3 counter passes over a child run of this script
+# ---------------------------------------------------------------------------------------------------------------------
+def _kernel_short_name(full):
+    """the probe's / tools/traffic_summary.py's spelling of a rocprofv3 Kernel_Name"""
+    return full.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+
+
+def live_traffic(dom, precision, args, budget_s=170):
+    """(bytes per launch, source note) for kernel `dom`, or (None, reason).  FETCH_SIZE and WRITE_SIZE do not fit one pass: each gets
+    its own `rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 1 ...` child (eager launches of the same workload,
+    counters only for kernels of `dom`'s family, nothing else traced), run from /tmp.  Units and the gfx950 correction as in
+    MI355X_MICROARCH.md (HBM / rocprofv3): both counters in KiB, summed over the 8 XCD instances of a dispatch; FETCH_SIZE x 2
+    (a wide streaming read is tallied at half its bytes); WRITE_SIZE exact."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    family = re.escape(dom.split("<")[0])
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--res", str(args.res), "--batch", str(args.batch),
+             "--alpha", str(args.alpha), "--precision", precision, "--graph", "0", "--sub-record", "0", "--no-cpu-baseline", "--no-probe",
+             "--live-traffic", "0"]
+    per_launch = {}
+    t_end = time.perf_counter() + budget_s
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        left = t_end - time.perf_counter()
+        if left < 20:
+            return None, "time budget of the counter passes exhausted"
+        d = tempfile.mkdtemp(prefix="ngan_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-include-regex", family, "--output-format", "csv", "-d", d, "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=left, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
+            by_dispatch = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter and _kernel_short_name(row["Kernel_Name"]) == dom:
+                            by_dispatch[row["Dispatch_Id"]] = by_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not by_dispatch:
+                return None, f"no {counter} rows for {dom}"
+            per_launch[counter] = (sum(by_dispatch.values()) / len(by_dispatch) * 1024.0, len(by_dispatch))
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} pass exceeded its time budget"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = 2.0 * per_launch["FETCH_SIZE"][0], per_launch["WRITE_SIZE"][0]
+    return rd + wr, (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, {per_launch['FETCH_SIZE'][1]} launches each) over a child "
+                     f"run of this command in this invocation; read {rd / 1e6:.1f} MB (FETCH_SIZE x 2, gfx950) + written {wr / 1e6:.1f} MB")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # one timed run in one arithmetic mode
 # ---------------------------------------------------------------------------------------------------------------------
 def run_mode(pkg, args, precision, device, world, rank, use_dist):
@@ -318,8 +378,17 @@ def run_mode(pkg, args, precision, device, world, rank, use_dist):
         # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3
         # passes over this same command; committed summary, see profiles/README.md).  null if no summary for this mode.
         traffic, traffic_src = None, None
+        live_note = None
+        if args.live_traffic != 0 and world == 1 and not args.force_dist and precision == args.precision:
+            try:
+                traffic, traffic_src = live_traffic(dom, precision, args)
+            except Exception as e:      # the counters are evidence, never a reason to lose the line
+                traffic, traffic_src = None, f"{type(e).__name__}: {e}"
+            if traffic is None:
+                live_note, traffic_src = traffic_src, None
+                print(f"[bench] live counter passes unavailable ({live_note}); falling back to the committed summary", file=sys.stderr)
         tfile = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_traffic_{precision}.json")
-        if os.path.exists(tfile) and args.res == 512 and args.batch == 16:
+        if traffic is None and os.path.exists(tfile) and args.res == 512 and args.batch == 16:
             with open(tfile) as fh:
                 tk = json.load(fh)["kernels"].get(dom)
             if tk:
@@ -422,6 +491,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient exchange even with one rank (path test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="do not time the dominant kernel with HIP events")
+    ap.add_argument("--live-traffic", type=int, default=-1, help="roofline.traffic of the headline's dominant kernel from two rocprofv3 counter "
+                    "passes over a child run, inside this invocation (one GPU only); 0: use the committed summary under profiles/")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, all-reduce over gloo on the CPU, print one line (no GPU)")
     args = ap.parse_args()
 
