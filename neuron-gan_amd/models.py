@@ -342,11 +342,12 @@ def _conv_any_width(x, m, res, slope):
     return y
 
 
-def _exec(steps, x, link=None, to_image=None):
+def _exec(steps, x, link=None, to_image=None, then=None):
     """Run planned steps on a channels-last tensor (or on latents for the stem).  `link`: PNLink of the LeakyReLU->PixelNorm that
     produced x, if x has no other consumer.  Returns (output, link of the output).  Inside `ops.first_order_only()` consecutive
     LeakyReLU->PixelNorm producers and conv consumers are linked (ops.PNLink).  `to_image`: a ToImage module applied to the result;
-    where the last step is a fused conv and the shape allows it, conv + ToImage run as one kernel (ops.ConvLReLUPNToImage)."""
+    where the last step is a fused conv and the shape allows it, conv + ToImage run as one kernel (ops.ConvLReLUPNToImage).
+    `then`: the planned step the caller will run on the result (the critic runs its first block and the rest as two calls)."""
     linking = ops.first_order_enabled() and torch.is_grad_enabled()
     last = len(steps) - 1
     for idx, st in enumerate(steps):
@@ -364,7 +365,7 @@ def _exec(steps, x, link=None, to_image=None):
                 return t, None
             out_link = ops.PNLink() if linking else None
             # the next step is an avg-pooled conv: ask this conv's kernel for the pooled copy of its output (ops._run_conv)
-            nxt = steps[idx + 1] if idx < last else None
+            nxt = steps[idx + 1] if idx < last else then
             pool_out = (nxt is not None and nxt[0] in ('conv_lrelu_pn', 'conv') and len(nxt) > 2 and nxt[2] == ops.RES_POOL2
                         and not _odd_width(nxt[1]))
             if pool_out:
@@ -629,12 +630,13 @@ class Discriminator_PG(_ProgressiveNet):
             return _exec(_plan(self.layers), y)[0]
         first = self.layers[0]
         if isinstance(first, Conv2d_scale_block):
-            y, link = self._from_image_then_block(self.FromIm, first, x)
-            return _exec(_plan(list(self.layers)[1:]), y, link)[0]
+            rest = _plan(list(self.layers)[1:])
+            y, link = self._from_image_then_block(self.FromIm, first, x, then=rest[0] if rest else None)
+            return _exec(rest, y, link)[0]
         return _exec(_plan(self.layers), self.FromIm.nhwc(x))[0]
 
     @staticmethod
-    def _from_image_then_block(from_im, block, x):
+    def _from_image_then_block(from_im, block, x, then=None):
         """block(FromImage(x)) for a down-sampling block -> (output, its PNLink).  FromImage is affine per pixel and AvgPool2d is
         linear, so pool(FromImage(x)) == FromImage(pool(x)): the image is pooled while FromImage loads it and the block's first
         conv runs without resampling -- the C-channel tensor at the image's full resolution is never written."""
@@ -647,8 +649,8 @@ class Discriminator_PG(_ProgressiveNet):
             link = ops.PNLink() if torch.is_grad_enabled() else None
             y, _ = ops.FirstBlock.apply(x, from_im.conv.weight, from_im.conv.bias, first[1].weight, first[1].bias, pool,
                                         first[1].scale_value, first[3], link)
-            return _exec(steps[1:], y, link)
-        return _exec(steps, from_im.nhwc(x, pool=pool))
+            return _exec(steps[1:], y, link, then=then)
+        return _exec(steps, from_im.nhwc(x, pool=pool), then=then)
 
     def _merge_pending_block(self):
         self.layers.insert(0, self.conv_block_list.pop(-1))

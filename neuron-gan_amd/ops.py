@@ -664,11 +664,17 @@ class ConvDgrad(Function):
     def backward(ctx, h):
         g, weight = ctx.saved_tensors
         resample, scale = ctx.cfg
-        gg = Conv.apply(h, weight, None, resample, scale) if ctx.needs_input_grad[0] else None
+        kept = []
+        if not ctx.needs_input_grad[0]:
+            gg = None
+        elif torch.is_grad_enabled():
+            gg = Conv.apply(h, weight, None, resample, scale)
+        else:       # the usual case (the penalty's second pass): no node to record, and the pooled copy of h serves the weight gradient too
+            gg = _run_conv(_c(h), weight, None, resample, scale, 0, 0.0, keep_pooled=kept)[0]
         gw = None
         if ctx.needs_input_grad[1]:
             if _accumulates_in_place(weight):
-                _run_wgrad(_c(h), g, resample, scale, accumulate_into=weight.grad, role=1)
+                _run_wgrad(_c(h), g, resample, scale, accumulate_into=weight.grad, role=1, pooled=kept[0] if kept else None)
             else:
                 gw = ConvWgrad.apply(h, g, resample, scale)
         return gg, gw, None, None
