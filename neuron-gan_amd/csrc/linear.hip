@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
 // lane instead costs one cache line per lane per load: 23 us for a 2 MB input.)
 __global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const float* __restrict__ y, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int S2, int C, float scale, int use_lds) {
+                                                             int S2, int C, float scale, int use_lds, int lg_s2, int lg_c) {
+    // lg_s2 / lg_c: log2 of S2 / C when they are powers of two (the usual 16 x 16 x 128 head), else -1.  With 16 - 32 blocks in
+    // flight the block's own instruction count is the launch's duration: 40 runtime integer divisions per thread were 8 of its 14 us
     extern __shared__ float wt[];
     __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -222,23 +224,39 @@ __global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const float* __rest
     float s = 0.f;
     if (use_lds) {
         const int CP = C + 1;
-        for (int e = tid; e < n; e += 1024) {
-            const int c = e / S2, p = e - c * S2;
-            wt[p * CP + c] = W[e];
+        // this sample's activations first: up to 32 loads per thread in flight while W is fetched and transposed (with the loads
+        // behind the transposition the block sat through two dependent rounds of memory latency: 14 us for 32 K elements)
+        constexpr int PRE = 32;
+        float yv[PRE];
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) yv[u] = tid + u * 1024 < n ? yb[tid + u * 1024] : 0.f;
+        if ((S2 & 3) == 0) {       // four positions of one channel per 16-byte load
+            for (int e = tid * 4; e < n; e += 4096) {
+                const int c = lg_s2 >= 0 ? e >> lg_s2 : e / S2, p = e - c * S2;
+                const float4 w = ld4(W + e);
+                wt[p * CP + c] = w.x; wt[(p + 1) * CP + c] = w.y; wt[(p + 2) * CP + c] = w.z; wt[(p + 3) * CP + c] = w.w;
+            }
+        } else {
+            for (int e = tid; e < n; e += 1024) {
+                const int c = e / S2, p = e - c * S2;
+                wt[p * CP + c] = W[e];
+            }
         }
         __syncthreads();
-        float a0 = 0.f, a1 = 0.f;
-        int e = tid;
-        for (; e + 1024 < n; e += 2048) {
-            const int p0 = e / C, c0 = e - p0 * C, p1 = (e + 1024) / C, c1 = e + 1024 - p1 * C;
-            a0 = fmaf(yb[e], wt[p0 * CP + c0], a0);
-            a1 = fmaf(yb[e + 1024], wt[p1 * CP + c1], a1);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int i = tid + u * 1024;
+            if (i < n) {
+                const int p0 = lg_c >= 0 ? i >> lg_c : i / C, c0 = i - p0 * C;
+                a[u & 3] = fmaf(yv[u], wt[p0 * CP + c0], a[u & 3]);
+            }
         }
-        if (e < n) {
+        for (int e = tid + PRE * 1024; e < n; e += 1024) {
             const int p0 = e / C, c0 = e - p0 * C;
-            a0 = fmaf(yb[e], wt[p0 * CP + c0], a0);
+            a[0] = fmaf(yb[e], wt[p0 * CP + c0], a[0]);
         }
-        s = a0 + a1;
+        s = (a[0] + a[1]) + (a[2] + a[3]);
     } else {
         for (int e = tid; e < n; e += 1024) {
             const int p = e / C, c = e - p * C;
@@ -271,12 +289,21 @@ __global__ void final_dot_dx_kernel(const float* __restrict__ go, const float* _
 __global__ void final_dot_dw_kernel(const float* __restrict__ y, const float* __restrict__ go, float* __restrict__ gW,
                                     float* __restrict__ gb, int B, int S2, int C, float scale, int accumulate) {
     const long n = (long)S2 * C;                          // accumulate: bit 0 gW += , bit 1 gb +=
+    // a thread per element of y's (p, c) order: the B reads of a wave are contiguous (the gradient's own (c, p) order made every
+    // lane fetch a line of its own); the 4-byte stores scatter instead, once
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int p = (int)(i % S2);
-        const int c = (int)(i / S2);
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s = fmaf(go[b], y[(long)b * n + (long)p * C + c], s);
-        gW[i] = (accumulate & 1) ? gW[i] + s * scale : s * scale;
+        const int c = (int)(i % C);
+        const int p = (int)(i / C);
+        float s0 = 0.f, s1 = 0.f;
+        int b = 0;
+        for (; b + 1 < B; b += 2) {
+            s0 = fmaf(go[b], y[(long)b * n + i], s0);
+            s1 = fmaf(go[b + 1], y[(long)(b + 1) * n + i], s1);
+        }
+        if (b < B) s0 = fmaf(go[b], y[(long)b * n + i], s0);
+        const float s = s0 + s1;
+        float* o = gW + (long)c * S2 + p;
+        *o = (accumulate & 1) ? *o + s * scale : s * scale;
     }
     if (gb && blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
@@ -365,7 +392,9 @@ extern "C" int ngan_final_dot_fwd(const float* y, const float* W, const float* b
         NGAN_REQUIRE(e == hipSuccess, (int)e, "final_dot_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(final_dot_fwd_kernel, dim3(B), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, y, W, bias, out, S2, C, scale, use_lds);
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    hipLaunchKernelGGL(final_dot_fwd_kernel, dim3(B), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, y, W, bias, out, S2, C, scale, use_lds,
+                       lg(S2), lg(C));
     return ngan::launch_status("ngan_final_dot_fwd");
 }
 

@@ -853,6 +853,7 @@ class FirstBlock(Function):
 
     @staticmethod
     def forward(ctx, x, w_from, b_from, weight, bias, pool, scale, slope, out_link=None):
+        ctx.set_materialize_grads(False)     # (no zero tensor for the norm output's absent gradient: a fill launch per backward)
         x = _c(x)
         b, h, wd = _from_image_out_hw(x, pool)
         n, c = weight.shape[0], weight.shape[1]
@@ -876,6 +877,8 @@ class FirstBlock(Function):
     def backward(ctx, gy, gr):
         p, w_from, b_from, weight, y, rn, tables = ctx.saved_tensors
         pool, scale, slope, has_bias = ctx.cfg
+        if gy is None:
+            return (None,) * 9
         b, h, wd, n = y.shape
         c = weight.shape[1]
         if ctx.out_link is not None and ctx.out_link.fused:
@@ -1108,6 +1111,7 @@ class LinearLReLUPN(Function):
 
     @staticmethod
     def forward(ctx, z, weight, size, scale, slope, out_link=None):
+        ctx.set_materialize_grads(False)
         z = _c(z)
         b, k = z.shape
         s2 = size * size
@@ -1129,6 +1133,8 @@ class LinearLReLUPN(Function):
     def backward(ctx, gy, _gr):
         z, weight, y, rn = ctx.saved_tensors
         s2, c, scale, slope = ctx.cfg
+        if gy is None:
+            return (None,) * ctx.n_in
         b, k = z.shape
         gy = _c(gy)
         if ctx.out_link is not None and ctx.out_link.fused:
@@ -1315,6 +1321,7 @@ class GradPenaltyHead(Function):
 
     @staticmethod
     def forward(ctx, g, lam):
+        ctx.set_materialize_grads(False)
         g = _c(g)
         b = g.shape[0]
         norms = torch.empty(b, device=g.device, dtype=torch.float32)
@@ -1331,6 +1338,8 @@ class GradPenaltyHead(Function):
     @once_differentiable
     def backward(ctx, gp, _gn):
         g, norms = ctx.saved_tensors
+        if gp is None:
+            return None, None
         b = g.shape[0]
         coef = torch.empty(b, device=g.device, dtype=torch.float32)
         _C.call("ngan_gp_coef", norms, b, ctx.lam, _c(gp), coef)

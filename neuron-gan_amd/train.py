@@ -252,6 +252,7 @@ class PGGANTrainer:
             self.enable_fused_stem()
         self.force_exchange = False
         self.last_z_g = None
+        self._one = torch.ones((), device=self.device)
         # collectives of the RCCL backend run on a stream of their own (see _on_comm_stream); created on first need
         self._comm_stream = None
         self.comm_timing = None     # bench.py: a list that receives (tag, start event, end event) of every gradient exchange
@@ -384,8 +385,8 @@ class PGGANTrainer:
         # reproducible from iteration to iteration (ops.flush_wgrad), and the step driver is meant to be bit-reproducible.
         with ops.deferred_wgrad():   # weight-gradient slabs of the whole pass are reduced by one launch at the end
             if gp.requires_grad:
-                gp.backward()
-            loss.backward()
+                gp.backward(gradient=self._one)     # (an explicit root gradient: autograd otherwise fills a ones tensor per call)
+            loss.backward(gradient=self._one)
         loss = loss.detach() + gp.detach()
         return {"D_loss": loss.detach(), "score_real": s_real.detach(), "score_fake": s_fake.detach(), "D_grad_pen": gp.detach()}
 
@@ -414,7 +415,7 @@ class PGGANTrainer:
             ops.linear_grad_sink = self.stem.sink if self._stem_sink_active else None
             try:
                 with ops.deferred_wgrad():
-                    loss.backward()  # train.py:384
+                    loss.backward(gradient=self._one)  # train.py:384
             finally:
                 ops.linear_grad_sink = None
         finally:
