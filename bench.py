@@ -235,14 +235,28 @@ def _kernel_short_name(full):
     return full.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
 
 
+def counter_bytes_per_launch(out_dir, counter, dom):
+    """(mean bytes per launch, launches) of `counter` for kernel `dom` from the counter_collection.csv files rocprofv3 left under
+    out_dir: one row per dispatch and XCD instance, values in KiB -- summed per dispatch, averaged over the dispatches."""
+    import csv
+    import glob
+    by_dispatch = {}
+    for f in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == counter and _kernel_short_name(row["Kernel_Name"]) == dom:
+                    by_dispatch[row["Dispatch_Id"]] = by_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+    if not by_dispatch:
+        return None
+    return sum(by_dispatch.values()) / len(by_dispatch) * 1024.0, len(by_dispatch)
+
+
 def live_traffic(dom, precision, args, budget_s=170):
     """(bytes per launch, source note) for kernel `dom`, or (None, reason).  FETCH_SIZE and WRITE_SIZE do not fit one pass: each gets
     its own `rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 1 ...` child (eager launches of the same workload,
     counters only for kernels of `dom`'s family, nothing else traced), run from /tmp.  Units and the gfx950 correction as in
     MI355X_MICROARCH.md (HBM / rocprofv3): both counters in KiB, summed over the 8 XCD instances of a dispatch; FETCH_SIZE x 2
     (a wide streaming read is tallied at half its bytes); WRITE_SIZE exact."""
-    import csv
-    import glob
     import re
     import shutil
     import subprocess
@@ -267,15 +281,10 @@ def live_traffic(dom, precision, args, budget_s=170):
                                stderr=subprocess.PIPE)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
-            by_dispatch = {}
-            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-                with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == counter and _kernel_short_name(row["Kernel_Name"]) == dom:
-                            by_dispatch[row["Dispatch_Id"]] = by_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
-            if not by_dispatch:
+            got = counter_bytes_per_launch(d, counter, dom)
+            if got is None:
                 return None, f"no {counter} rows for {dom}"
-            per_launch[counter] = (sum(by_dispatch.values()) / len(by_dispatch) * 1024.0, len(by_dispatch))
+            per_launch[counter] = got
         except subprocess.TimeoutExpired:
             return None, f"rocprofv3 --pmc {counter} pass exceeded its time budget"
         finally:

@@ -278,3 +278,27 @@ def test_epoch_schedule_follows_the_reference_epoch_by_epoch(ngan):
         if lr is not None:
             tr.opt_g.set_lr(lr)
             tr.opt_d.set_lr(lr)
+
+
+def test_counter_rows_become_bytes_per_launch(tmp_path):
+    """bench.py's live HBM-traffic figure: rocprofv3 writes one row per dispatch and XCD instance, in KiB; the kernel's launches are
+    summed over the instances, averaged over the dispatches, and other kernels / counters are ignored."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = tmp_path / "run" / "host"
+    d.mkdir(parents=True)
+    full = "void (anonymous namespace)::wgrad_f32_kernel<1, 1, 0, 32, 4, 1, 1>((anonymous namespace)::WgradArgs)"
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    for disp, per_xcd in ((7, 100.0), (9, 300.0)):
+        rows += [f'{disp},"{full}",FETCH_SIZE,{per_xcd}' for _ in range(8)]
+    rows += ['11,"void (anonymous namespace)::conv3x3_tile_kernel<1, 1, 0, 0, 2>(ngan::ConvArgs, int)",FETCH_SIZE,999.0',
+             f'7,"{full}",WRITE_SIZE,5.0']
+    (d / "123_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    dom = bench._kernel_short_name(full)
+    assert dom == "wgrad_f32_kernel<1, 1, 0, 32, 4, 1, 1>"
+    got = bench.counter_bytes_per_launch(str(tmp_path), "FETCH_SIZE", dom)
+    assert got == ((8 * 100.0 + 8 * 300.0) / 2 * 1024.0, 2)
+    assert bench.counter_bytes_per_launch(str(tmp_path), "WRITE_SIZE", dom) == (5.0 * 1024.0, 1)
+    assert bench.counter_bytes_per_launch(str(tmp_path), "FETCH_SIZE", "no_such_kernel") is None
