@@ -393,12 +393,6 @@ class deferred_wgrad:
         return False
 
 
-# A/B switch (off by default: measured): weight gradients of layers with at most this many pixels go to a side stream
-_side_wgrad_pixels = int(_diag_env("NGAN_WGRAD_SIDE_PIXELS", "0"))
-_side_stream = None
-_side_keep = []
-
-
 def flush_wgrad():
     """Reduce every pending slab set.  The contributions to one gradient are summed in a CANONICAL order (by the role of the node
     that produced them, then by arrival), not in the order autograd happened to run the nodes: that order is not reproducible for a
@@ -407,9 +401,6 @@ def flush_wgrad():
     iteration to the next) and a floating-point sum depends on it in the last bit."""
     if not _pending:
         return 0
-    if _side_keep:
-        torch.cuda.current_stream().wait_stream(_side_stream)
-        _side_keep.clear()
     rec, n = b"", 0
     for e in _pending.values():
         src = sorted(e["sources"], key=lambda s: s[3])        # stable: equal roles keep their arrival order
@@ -438,19 +429,7 @@ def _run_wgrad(x, g, resample, scale, accumulate_into=None, role=0, pooled=None)
     gw = accumulate_into if accumulate_into is not None else torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
     ws = torch.empty(_C.wgrad_workspace_bytes(b, h, w, cin, cout) // 4, device=g.device, dtype=torch.float32)
     if accumulate_into is not None and _defer_depth > 0:
-        if _side_wgrad_pixels and b * h * w <= _side_wgrad_pixels and g.is_cuda:
-            # a small-image layer: its weight gradient under-fills the chip and so does the input-gradient kernel of the next
-            # layer down -- the slabs are written on a side stream beside it (joined in flush_wgrad, where the operands are released)
-            global _side_stream
-            if _side_stream is None:
-                _side_stream = torch.cuda.Stream(device=g.device)
-            cur = torch.cuda.current_stream()
-            _side_stream.wait_stream(cur)
-            with torch.cuda.stream(_side_stream):
-                _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 2, _conv_precision)
-            _side_keep.append((x, g))
-        else:
-            _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 2, _conv_precision)
+        _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 2, _conv_precision)
         plan = _C.wgrad_plan(b, h, w, cin, cout, _conv_precision)
         e = _pending.setdefault(gw.data_ptr(), dict(gw=gw, plan=plan, cin=cin, sources=[]))
         e["sources"].append((ws, plan[0], float(scale), role))
