@@ -40,6 +40,21 @@ def test_invalid_arguments_return_status_not_crash(built):
     assert built._C.wgrad_workspace_bytes(1, 8, 8, 12, 16) == 0
 
 
+def test_in_place_entry_points_validate_on_the_host(built):
+    """the accumulate-into-.grad forms and the stem's Adam-epilogue launch reject bad arguments before anything is launched"""
+    lib = built._C.lib()
+    assert lib.ngan_channel_sum_acc(None, None, None, 16, 16, 1.0, 1, None) < 0
+    assert lib.ngan_final_dot_dw_acc(None, None, None, None, 1, 16, 16, 1.0, 3, None) < 0
+    assert lib.ngan_from_image_dw_acc(None, None, None, None, None, 1, 8, 8, 1, 16, 0, 3, None) < 0
+    assert lib.ngan_linear_wgrad_adam(None, None, None, None, None, None, None, 16, 512, 256, 128, 1.0, None) < 0
+    assert b"null" in lib.ngan_last_error()
+    # a contraction the MFMA form does not take (K must be a multiple of 16, at most 512): refused, not mis-launched
+    import ctypes
+    one = ctypes.c_void_p(16)        # any non-null address: the shape check comes before the launch
+    assert lib.ngan_linear_wgrad_adam(one, one, one, one, one, one, one, 16, 520, 256, 128, 1.0, None) < 0
+    assert b"K=520" in lib.ngan_last_error()
+
+
 def test_wide_layers_are_cut_into_kernel_sized_chunks(ngan):
     """A conv launch takes 16 / 32 / 64 / 128 output channels (include/ngan.h); the reference's wide presets (configs/config.py:87-98)
     and any other multiple of 16 run as chunks of those sizes, largest first, covering every channel exactly once."""
