@@ -251,7 +251,7 @@ def counter_bytes_per_launch(out_dir, counter, dom):
     return sum(by_dispatch.values()) / len(by_dispatch) * 1024.0, len(by_dispatch)
 
 
-def live_traffic(dom, precision, args, budget_s=170):
+def live_traffic(dom, precision, args, budget_s=90):
     """(bytes per launch, source note) for kernel `dom`, or (None, reason).  FETCH_SIZE and WRITE_SIZE do not fit one pass: each gets
     its own `rocprofv3 --pmc <counter> -- python3 bench.py --steps 1 --warmup 1 ...` child (eager launches of the same workload,
     counters only for kernels of `dom`'s family, nothing else traced), run from /tmp.  Units and the gfx950 correction as in
@@ -276,17 +276,26 @@ def live_traffic(dom, precision, args, budget_s=170):
             return None, "time budget of the counter passes exhausted"
         d = tempfile.mkdtemp(prefix="ngan_pmc_", dir="/tmp")
         try:
-            r = subprocess.run([exe, "--pmc", counter, "--kernel-include-regex", family, "--output-format", "csv", "-d", d, "--"] + child,
-                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=left, stdout=subprocess.DEVNULL,
-                               stderr=subprocess.PIPE)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
+            # a session of its own, so that a pass that overruns its budget is ended as a whole (profiler AND profiled child)
+            proc = subprocess.Popen([exe, "--pmc", counter, "--kernel-include-regex", family, "--output-format", "csv", "-d", d, "--"] + child,
+                                    cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                    start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)      # exactly the process group started above
+                except ProcessLookupError:
+                    pass
+                proc.communicate()
+                return None, f"rocprofv3 --pmc {counter} pass exceeded its time budget"
+            if proc.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited with {proc.returncode}: {err.decode(errors='replace')[-200:]}"
             got = counter_bytes_per_launch(d, counter, dom)
             if got is None:
                 return None, f"no {counter} rows for {dom}"
             per_launch[counter] = got
-        except subprocess.TimeoutExpired:
-            return None, f"rocprofv3 --pmc {counter} pass exceeded its time budget"
         finally:
             shutil.rmtree(d, ignore_errors=True)
     rd, wr = 2.0 * per_launch["FETCH_SIZE"][0], per_launch["WRITE_SIZE"][0]
