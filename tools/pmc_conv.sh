@@ -20,7 +20,7 @@ for f in glob.glob(f"{R}/gpurun_out/pmc_{tag}_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if ("conv3x3" not in r["Kernel_Name"] and "wgrad_" not in r["Kernel_Name"]) or "pack" in r["Kernel_Name"] or "reduce" in r["Kernel_Name"]:
             continue
-        k = (r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])
+        k = (r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][-60:], r["Counter_Name"])
         d = tot.setdefault(k, [0, 0.0])
         d[0] += 1
         d[1] += float(r["Counter_Value"])
