@@ -58,16 +58,19 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // One element of optim.Adam.step (train.py:224-225: betas (beta1, 0.999), eps 1e-8, no weight decay, no amsgrad) -- shared by the flat
 // multi-tensor kernel (adam.hip) and the generator stem's gradient-free update (linear.hip), so both produce the same bits.
-struct AdamCoef { float b1, b2, eps, gscale, step_size, inv_sqrt_bc2; };
+// hyper = {lr, beta1, beta2, eps, grad_scale, 1 - beta1, 1 - beta2}: the last two are rounded from the host's double difference, as
+// torch rounds the Python-side `1 - beta` it passes to lerp_ / addcmul_ (1.0f - 0.999f is 1.3e-5 off 0.001f: every exp_avg_sq
+// would carry that factor)
+struct AdamCoef { float b2, omb1, omb2, eps, gscale, step_size, inv_sqrt_bc2; };
 __device__ __forceinline__ AdamCoef adam_coef(const float* __restrict__ hyper, float t) {
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2];
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    return AdamCoef{b1, b2, hyper[3], hyper[4], lr / bc1, 1.0f / sqrtf(bc2)};
+    return AdamCoef{b2, hyper[5], hyper[6], hyper[3], hyper[4], lr / bc1, 1.0f / sqrtf(bc2)};
 }
 __device__ __forceinline__ void adam_update(const AdamCoef& k, float g, float& p, float& m, float& v) {
     const float gv = g * k.gscale;                                 // 1/world_size after a SUM exchange, else 1
-    const float mv = fmaf(1.0f - k.b1, gv - m, m);                 // m.lerp_(g, 1 - beta1)
-    const float vv = fmaf(k.b2, v, (1.0f - k.b2) * gv * gv);      // v.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float mv = fmaf(k.omb1, gv - m, m);                      // m.lerp_(g, 1 - beta1)
+    const float vv = fmaf(k.b2, v, k.omb2 * gv * gv);             // v.mul_(beta2).addcmul_(g, g, 1 - beta2)
     m = mv;
     v = vv;
     p -= k.step_size * (mv / (sqrtf(vv) * k.inv_sqrt_bc2 + k.eps));   // p.addcdiv_(m, sqrt(v)/sqrt(bc2) + eps, -lr/bc1)

@@ -480,6 +480,39 @@ def test_linear_stem(ngan, B, K, S, C):
     run_both(f_hip, f_ref, t, ["z", "w"])
 
 
+@pytest.mark.parametrize("B,K,S2,C,gscale", [(16, 512, 256, 128, 1.0), (24, 64, 16, 32, 0.5), (7, 48, 9, 20, 1.0)])
+def test_stem_adam_epilogue_against_torch_adam(ngan, B, K, S2, C, gscale):
+    """ngan_linear_wgrad_adam: Adam applied to the stem weight in the epilogue of its gradient's factor product (no stored gradient),
+    three consecutive steps, against torch.optim.Adam fed the fp64 gradient  scale * gscale * sum_b gc[b] (x) z[b]  (row c*S2 + p of
+    the weight pairs with gc[b][p][c]: models.py:299-311's Unflatten)."""
+    C_ = ngan._C
+    torch.manual_seed(12)
+    rows = C * S2
+    w = (torch.randn(rows, K) * 0.1)
+    p = w.clone().to(DEV)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    lr, b1, b2, eps, scale = 1e-3, 0.5, 0.999, 1e-8, 0.0613
+    hyper = torch.tensor([lr, b1, b2, eps, gscale, 1.0 - b1, 1.0 - b2], dtype=torch.float32, device=DEV)
+    step = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ref = torch.nn.Parameter(w.double())
+    opt = torch.optim.Adam([ref], lr=lr, betas=(b1, b2), eps=eps)
+    for it in range(3):
+        z = torch.randn(B, K)
+        gc = torch.randn(B, S2, C)
+        ref.grad = scale * gscale * torch.einsum("bpc,bk->cpk", gc.double(), z.double()).reshape(rows, K)
+        opt.step()
+        step += 1                                        # ngan_adam_step's advance launch does this for every active tensor
+        C_.call("ngan_linear_wgrad_adam", z.to(DEV), gc.to(DEV), p, m, v, step, hyper, B, K, S2, C, scale)
+        # a step moves every element by ~lr * g / |g|.  Where the fp32 and the fp64 gradient agree to 1e-7 of the tensor's scale the
+        # two updates agree to ~1e-9 (measured); an element whose gradient is itself ~1e-7 of that scale may move by up to lr the
+        # other way (measured: a few dozen of 16.8 M, worst 4e-5 = 0.04 lr): bound their share and the mean
+        diff = (p.cpu().double() - ref.detach()).abs()
+        assert float((diff > 0.02 * lr).double().mean()) < 2e-4 and float(diff.mean()) < 1e-4 * lr * (it + 1), (it, float(diff.max()))
+        assert float(diff.max()) < 1.01 * lr * (it + 1), it
+    assert rel(m.cpu(), opt.state[ref]["exp_avg"]) < 1e-5 and rel(v.cpu(), opt.state[ref]["exp_avg_sq"]) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(4, 1, 32, 32), (3, 1, 6, 6), (16, 1, 512, 512)])
 def test_sample_l2norm(ngan, shape):
     ops = ngan.ops
