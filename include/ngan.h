@@ -267,8 +267,9 @@ int ngan_final_dot_dw_acc(const float* y, const float* go, float* gW, float* gb,
  *   seg_off[i], seg_len[i]  element offset / length of tensor i inside p, g, m, v   (device, int64)
  *   seg_active[i]           1 if tensor i received a gradient this step (inactive tensors keep step and state)
  *   seg_step[i]             per-tensor step count (device float, incremented here for active tensors)
- *   hyper                   7 device floats {lr, beta1, beta2, eps, grad_scale, 1 - beta1, 1 - beta2} (the last two rounded from the
- *                           host's double difference, as torch does); the gradient is multiplied by grad_scale
+ *   hyper                   9 device floats {lr, beta1, beta2, eps, grad_scale, 1 - beta1, 1 - beta2, ln beta1, ln beta2} (the last
+ *                           four rounded from the host's double values: torch forms `1 - beta` and its bias corrections in
+ *                           double; here 1 - beta^t = -expm1(t ln beta)); the gradient is multiplied by grad_scale
  *                           (1/world_size after a SUM all-reduce across data-parallel ranks, otherwise 1)
  * chunk_seg / chunk_off (device int32 / int64): work list, one entry per 4096-element chunk. */
 int ngan_adam_step(float* p, const float* g, float* m, float* v, const long* seg_off, const long* seg_len,

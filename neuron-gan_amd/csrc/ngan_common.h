@@ -58,13 +58,14 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // One element of optim.Adam.step (train.py:224-225: betas (beta1, 0.999), eps 1e-8, no weight decay, no amsgrad) -- shared by the flat
 // multi-tensor kernel (adam.hip) and the generator stem's gradient-free update (linear.hip), so both produce the same bits.
-// hyper = {lr, beta1, beta2, eps, grad_scale, 1 - beta1, 1 - beta2}: the last two are rounded from the host's double difference, as
-// torch rounds the Python-side `1 - beta` it passes to lerp_ / addcmul_ (1.0f - 0.999f is 1.3e-5 off 0.001f: every exp_avg_sq
-// would carry that factor)
+// hyper = {lr, beta1, beta2, eps, grad_scale, 1 - beta1, 1 - beta2, ln beta1, ln beta2}: the last four are rounded from the host's
+// double values, as torch rounds the Python-side `1 - beta` it passes to lerp_ / addcmul_ and forms its bias corrections in double
+// (1.0f - 0.999f is 1.3e-5 off 0.001f: every exp_avg_sq, and the first steps' 1 - beta2^t, would carry that factor).  The step count
+// lives on the device (graph replay), so the bias corrections are formed here: 1 - beta^t = -expm1(t ln beta), good to ~1e-7.
 struct AdamCoef { float b2, omb1, omb2, eps, gscale, step_size, inv_sqrt_bc2; };
 __device__ __forceinline__ AdamCoef adam_coef(const float* __restrict__ hyper, float t) {
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2];
-    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    const float lr = hyper[0], b2 = hyper[2];
+    const float bc1 = -expm1f(t * hyper[7]), bc2 = -expm1f(t * hyper[8]);
     return AdamCoef{b2, hyper[5], hyper[6], hyper[3], hyper[4], lr / bc1, 1.0f / sqrtf(bc2)};
 }
 __device__ __forceinline__ void adam_update(const AdamCoef& k, float g, float& p, float& m, float& v) {

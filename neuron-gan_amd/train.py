@@ -88,8 +88,9 @@ class FusedAdam:
 
     def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.5, 0.999), eps=1e-8):
         self.flat = flat
-        # {lr, beta1, beta2, eps, grad_scale, 1 - beta1, 1 - beta2}: include/ngan.h, ngan_adam_step
-        self.hyper_host = [float(lr), float(betas[0]), float(betas[1]), float(eps), 1.0, 1.0 - float(betas[0]), 1.0 - float(betas[1])]
+        # {lr, beta1, beta2, eps, grad_scale, 1 - beta1, 1 - beta2, ln beta1, ln beta2}: include/ngan.h, ngan_adam_step
+        self.hyper_host = [float(lr), float(betas[0]), float(betas[1]), float(eps), 1.0, 1.0 - float(betas[0]), 1.0 - float(betas[1]),
+                           *(math.log(float(b)) if float(b) > 0 else float("-inf") for b in betas)]     # (beta = 0: 1 - 0^t = 1)
         self.hyper = torch.tensor(self.hyper_host, dtype=torch.float32, device=flat.flat.device)
         self.param_groups = [{"lr": float(lr)}]  # same handle the reference's update_lr() writes to (train.py:253-265)
 

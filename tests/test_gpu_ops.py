@@ -493,7 +493,7 @@ def test_stem_adam_epilogue_against_torch_adam(ngan, B, K, S2, C, gscale):
     m = torch.zeros_like(p)
     v = torch.zeros_like(p)
     lr, b1, b2, eps, scale = 1e-3, 0.5, 0.999, 1e-8, 0.0613
-    hyper = torch.tensor([lr, b1, b2, eps, gscale, 1.0 - b1, 1.0 - b2], dtype=torch.float32, device=DEV)
+    hyper = torch.tensor([lr, b1, b2, eps, gscale, 1.0 - b1, 1.0 - b2, np.log(b1), np.log(b2)], dtype=torch.float32, device=DEV)
     step = torch.zeros(1, dtype=torch.float32, device=DEV)
     ref = torch.nn.Parameter(w.double())
     opt = torch.optim.Adam([ref], lr=lr, betas=(b1, b2), eps=eps)
