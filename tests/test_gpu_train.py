@@ -244,6 +244,39 @@ def test_small_gradients_added_in_place_equal_autograds_accumulation(ngan, monke
     assert all(float(p.grad.abs().max()) > 0 for p in a.flat_d.params if p.numel() < 64 and a.flat_d.active_host[a.flat_d.index[id(p)]])
 
 
+def test_flat_adam_against_torch_adam(ngan):
+    """FusedAdam (ngan_adam_step over the flat buffers) next to torch.optim.Adam on copies of the same tensors: five steps of random
+    gradients, one tensor without a gradient for the first two steps (torch skips `.grad is None` tensors, so its bias correction
+    starts later -- the per-tensor step count), sizes that are not multiples of the 4096-element chunk.  Same fp32 formulas: the
+    parameters agree to a few 1e-7 of a step's size."""
+    torch.manual_seed(17)
+    net = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(n, device=DEV) * 0.3) for n in (5000, 37, 4096, 12289)])
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in net]
+    lr = 2e-3
+    opt = torch.optim.Adam(ref, lr=lr, betas=(0.5, 0.999), eps=1e-8, foreach=False)
+    flat = ngan.train.FlatParams(net)
+    fa = ngan.train.FusedAdam(flat, lr, (0.5, 0.999))
+    for it in range(5):
+        late = it < 2                                      # tensor 1 joins at the third step
+        flat.set_active([p for i, p in enumerate(flat.params) if not (late and i == 1)])
+        flat.zero_grad()
+        for i, (p, r) in enumerate(zip(flat.params, ref)):
+            if late and i == 1:
+                r.grad = None
+                continue
+            g = torch.randn_like(p) * (10.0 ** (i - 2))    # gradient scales from 1e-2 to 10
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        fa.step()
+        opt.step()
+    torch.cuda.synchronize()
+    assert flat.seg_step.cpu().tolist() == [5.0, 3.0, 5.0, 5.0]
+    for i, (p, r) in enumerate(zip(flat.params, ref)):
+        d = float((p.detach() - r.detach()).abs().max())
+        assert d < 1e-4 * lr, (i, d)                       # five steps of ~lr each; measured: 3e-5 lr (two ulps of the parameter) at most,
+        assert float((p.detach() - r.detach()).abs().mean()) < 2e-6 * lr, i                            # 2.7e-7 lr on average
+
+
 def test_penalty_switched_off_draws_no_second_latent_batch(ngan):
     """grad_pen_lambda = 0 is the reference CLI's argparse default: D_grad_pen_loss returns 0 (loss_functions.py:179) and draws
     nothing.  The step driver must run (round 1 stacked a CPU scalar with device tensors) and must not generate the unused fakes."""
