@@ -453,11 +453,12 @@ def test_lerp_and_xhat(ngan):
     assert rel(got, eps * real + (1 - eps) * fake) < 1e-6
 
 
-def test_final_dot_all_orders(ngan):
+@pytest.mark.parametrize("B,C,S", [(3, 32, 4), (2, 20, 3), (5, 128, 16)])   # power-of-two sizes take shifts, 20 x 9 the division path; 128 x 256 = the default head
+def test_final_dot_all_orders(ngan, B, C, S):
     ops = ngan.ops
     torch.manual_seed(7)
-    t = {"x": torch.randn(3, 32, 4, 4), "w": torch.randn(1, 32, 4, 4), "b": torch.randn(1)}
-    scale = 0.11
+    t = {"x": torch.randn(B, C, S, S), "w": torch.randn(1, C, S, S), "b": torch.randn(1)}
+    scale = 2.5 / (C * S * S) ** 0.5          # scores of order one: the tanh in front of the loss must not saturate
     run_both(lambda d: torch.tanh(ops.FinalDot.apply(nhwc(d["x"]), d["w"], d["b"], scale)),
              lambda d: torch.tanh(F.conv2d(scale * d["x"], d["w"], d["b"]).flatten(1)), t, ["w", "b"], x_name="x")
 
