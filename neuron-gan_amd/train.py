@@ -162,11 +162,16 @@ class StemGradExchange:
         assert weight is self.weight
         self.captured = (z, gc, s2, c, scale)
 
-    def finish(self, run_collectives=None, materialize=True):
+    def finish(self, run_collectives=None, materialize=True, also=None):
         """all-gather the factors and (materialize) write the full-batch gradient into weight.grad (call after backward).
         `run_collectives(fn)` executes the collectives (the step driver passes its communication-stream runner,
-        PGGANTrainer._on_comm_stream).  With materialize=False the gradient is never formed: `self.factors` goes to the fused Adam."""
+        PGGANTrainer._on_comm_stream).  With materialize=False the gradient is never formed: `self.factors` goes to the fused Adam.
+        `also`: a further collective of the caller (the all-reduce of the generator's other gradients) issued in the SAME
+        communication-stream section: one hand-over between the streams per exchange instead of two."""
+        run = run_collectives or (lambda fn: fn())
         if self.captured is None:
+            if also is not None:
+                run(also)
             return
         z, gc, s2, c, scale = self.captured
         b, k = z.shape
@@ -181,8 +186,12 @@ class StemGradExchange:
             def gather():
                 dist.all_gather_into_tensor(zs, zc, group=self.group)
                 dist.all_gather_into_tensor(gs, gcc, group=self.group)
-            (run_collectives or (lambda fn: fn()))(gather)
+                if also is not None:
+                    also()
+            run(gather)
         else:
+            if also is not None:
+                run(also)
             zs, gs = z.contiguous(), gc.contiguous()
         self.factors = (zs, gs, s2, c, scale)
         if materialize:
@@ -356,9 +365,10 @@ class PGGANTrainer:
     def _exchange(self, flat):
         if flat is self.flat_g and self._stem_sink_active:
             # the stem occupies the head of G's flat buffer: gather its factors, all-reduce only the tail
-            self.stem.finish(lambda fn: self._on_comm_stream(fn, "generator"), materialize=not self._stem_grad_skipped)
+            tail = None
             if self.world > 1 or self.force_exchange:
-                self._on_comm_stream(lambda: dist.all_reduce(flat.grad[self._stem_elems:], op=dist.ReduceOp.SUM, group=self.group), "generator")
+                tail = lambda: dist.all_reduce(flat.grad[self._stem_elems:], op=dist.ReduceOp.SUM, group=self.group)   # noqa: E731
+            self.stem.finish(lambda fn: self._on_comm_stream(fn, "generator"), materialize=not self._stem_grad_skipped, also=tail)
             return
         if self.world > 1 or self.force_exchange:
             self._on_comm_stream(lambda: exchange_gradients(flat, self.world, self.group, force=self.force_exchange),
