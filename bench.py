@@ -25,7 +25,8 @@ Rank 0 prints ONE JSON line: images/s over all ranks, plus
                   `live_traffic`; `traffic_source` says so) with the committed summary (profiles/, tools/measure_round.sh) as the
                   fallback when the profiler cannot run
   cpu_baseline -- the CPU oracle (oracle/pggan_oracle.py, a port of the reference's path) timed on this host's cores on a
-                  bounded sample of the same workload at the same batch (N = 1 only), with the CPU model string.
+                  bounded sample of the same workload at the same batch (N = 1 only): one untimed warm-up iteration, then >= 2 timed
+                  ones (mean and per-iteration times in `sample` / `s_per_iteration`), with the CPU model string.
 
 Multi-GPU: `python bench.py --gpus N` without a launcher environment starts N child processes (RANK / LOCAL_RANK / WORLD_SIZE /
 MASTER_* set) BEFORE anything touches the GPU -- the parent never imports torch -- and exits with their worst exit code.
@@ -194,8 +195,10 @@ def cpu_model_name():
     return platform.processor() or platform.machine()
 
 
-def cpu_baseline(res, alpha, batch, budget_s=25.0, max_iters=4):
-    """Time the CPU oracle (port of the reference path) on this host at the bench's own batch; bounded sample of the same workload."""
+def cpu_baseline(res, alpha, batch, budget_s=45.0, min_timed=2, max_timed=4):
+    """Time the CPU oracle (port of the reference path, train.py:357-385) on this host at the bench's own batch: ONE untimed warm-up
+    iteration (allocator growth, oneDNN primitive creation and weight re-ordering happen there), then at least `min_timed` timed
+    iterations -- more while the next one still fits `budget_s` seconds of timed work.  Reports the mean and every iteration's time."""
     import torch
     from __graft_entry__ import load_package
     from oracle import pggan_oracle as O
@@ -214,17 +217,24 @@ def cpu_baseline(res, alpha, batch, budget_s=25.0, max_iters=4):
     cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     torch.manual_seed(123)
-    done, t0 = 0, time.perf_counter()
-    while True:
+
+    def one_iteration():
         x = torch.rand(batch, 1, res, res) * 2 - 1
         z = [O.sample_latent_vec((batch, 512)) for _ in range(3)]
+        t0 = time.perf_counter()
         O.train_step(pg, spec, pd, spec, og, od, x, z[0], z[1], torch.rand(batch, 1, 1, 1), z[2])
-        done += 1
-        el = time.perf_counter() - t0
-        if done >= max_iters or el + el / done > budget_s:     # stop when the next iteration would overrun the budget
-            break
-    return {"value": batch * done / el, "unit": "images/s", "cores": cores, "cpu_model": cpu_model_name(), "kind": "port",
-            "sample": f"{done} full iteration(s) of the oracle at {res}x{res}, batch {batch}, fp32, {cores} torch threads, {el:.1f} s"}
+        return time.perf_counter() - t0
+
+    warm = one_iteration()
+    times = []
+    while len(times) < min_timed or (len(times) < max_timed and sum(times) + max(times) <= budget_s):
+        times.append(one_iteration())
+    el = sum(times)
+    per = ", ".join(f"{t:.2f}" for t in times)
+    return {"value": batch * len(times) / el, "unit": "images/s", "cores": cores, "cpu_model": cpu_model_name(), "kind": "port",
+            "timed_iterations": len(times), "warmup_iterations": 1, "s_per_iteration": [round(t, 3) for t in times], "warmup_s": round(warm, 3),
+            "sample": f"1 untimed warm-up iteration ({warm:.2f} s) + {len(times)} timed full iterations of the oracle at {res}x{res}, batch {batch}, "
+                      f"fp32, {cores} torch threads: {per} s each, mean {el / len(times):.2f} s"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

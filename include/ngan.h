@@ -249,7 +249,7 @@ int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW, int B, int
  * seg_step points at its (already advanced) step count, hyper as in ngan_adam_step.  Replaces, for this tensor, the store in
  * ngan_linear_wgrad plus its chunks of ngan_adam_step: same arithmetic, same bits. */
 int ngan_linear_wgrad_adam(const float* z, const float* gc, float* p, float* m, float* v, const float* seg_step,
-                           const float* hyper, int B, int K, int S, int C, float scale, void* stream);
+                           const float* hyper, int n_hyper, int B, int K, int S, int C, float scale, void* stream);
 int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream);
 
 /* ---- critic head: Conv2d_normalized(C, 1, (S,S), padding 0) + Flatten, models.py:485-490 ------------------------
@@ -271,10 +271,14 @@ int ngan_final_dot_dw_acc(const float* y, const float* go, float* gW, float* gb,
  *                           four rounded from the host's double values: torch forms `1 - beta` and its bias corrections in
  *                           double; here 1 - beta^t = -expm1(t ln beta)); the gradient is multiplied by grad_scale
  *                           (1/world_size after a SUM all-reduce across data-parallel ranks, otherwise 1)
+ *   n_hyper                 the number of floats the caller put into `hyper`: must equal NGAN_ADAM_HYPER_FLOATS.  (`hyper` grew from 5
+ *                           to 9 floats in round 3; the count is checked so that a binding written against the older layout gets
+ *                           NGAN_ERR_ARG instead of a kernel that reads past its buffer.  ngan_linear_wgrad_adam takes the same pair.)
  * chunk_seg / chunk_off (device int32 / int64): work list, one entry per 4096-element chunk. */
+#define NGAN_ADAM_HYPER_FLOATS 9
 int ngan_adam_step(float* p, const float* g, float* m, float* v, const long* seg_off, const long* seg_len,
                    const int* seg_active, float* seg_step, int n_seg, const int* chunk_seg, const long* chunk_off,
-                   int n_chunks, const float* hyper, void* stream);
+                   int n_chunks, const float* hyper, int n_hyper, void* stream);
 
 /* ---- the critic's first layer pair as one operator (first-order passes): FromImage (ONE colour channel, models.py:161-165) folded
  * into the block's first 3x3 conv + LeakyReLU + PixelNorm (models.py:252-264).  f[c] = wf[c]*p + bf[c] is affine in one number per

@@ -53,7 +53,7 @@ SIGNATURES = {
     "ngan_linear_lrelu_pn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P],
     "ngan_linear_wgrad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ngan_linear_wgrad_acc": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
-    "ngan_linear_wgrad_adam": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "ngan_linear_wgrad_adam": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "ngan_linear_dgrad": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ngan_final_dot_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "ngan_final_dot_dx": [_P, _P, _P, _I, _I, _I, _F, _P],
@@ -61,7 +61,7 @@ SIGNATURES = {
     "ngan_final_dot_dw_acc": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "ngan_conv3x3_pack_many": [_P, _I, _L, _P],
     "ngan_conv3x3_wgrad_reduce_many": [_P, _I, _P],
-    "ngan_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
+    "ngan_adam_step": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "ngan_augment_batch": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ngan_conv3x3_up2_border": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "ngan_first_block_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P],

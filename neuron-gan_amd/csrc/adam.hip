@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 extern "C" int ngan_adam_step(float* p, const float* g, float* m, float* v, const long* seg_off, const long* seg_len,
                               const int* seg_active, float* seg_step, int n_seg, const int* chunk_seg, const long* chunk_off,
-                              int n_chunks, const float* hyper, void* stream) {
+                              int n_chunks, const float* hyper, int n_hyper, void* stream) {
     NGAN_REQUIRE(p && g && m && v && seg_off && seg_len && seg_active && seg_step && chunk_seg && chunk_off && hyper,
                  NGAN_ERR_ARG, "adam_step: null pointer");
+    NGAN_REQUIRE(n_hyper == NGAN_ADAM_HYPER_FLOATS, NGAN_ERR_ARG, "adam_step: hyper holds %d floats, this library reads %d (include/ngan.h)",
+                 n_hyper, NGAN_ADAM_HYPER_FLOATS);
     NGAN_REQUIRE(n_seg > 0 && n_chunks > 0, NGAN_ERR_SHAPE, "adam_step: n_seg=%d n_chunks=%d", n_seg, n_chunks);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_advance_kernel, dim3(ngan::ceil_div(n_seg, 256)), dim3(256), 0, s, seg_active, seg_step, n_seg);

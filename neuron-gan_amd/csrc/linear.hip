@@ -363,8 +363,10 @@ extern "C" int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW,
 }
 
 extern "C" int ngan_linear_wgrad_adam(const float* z, const float* gc, float* p, float* m, float* v, const float* seg_step,
-                                      const float* hyper, int B, int K, int S, int C, float scale, void* stream) {
+                                      const float* hyper, int n_hyper, int B, int K, int S, int C, float scale, void* stream) {
     NGAN_REQUIRE(z && gc && p && m && v && seg_step && hyper, NGAN_ERR_ARG, "linear_wgrad_adam: null pointer");
+    NGAN_REQUIRE(n_hyper == NGAN_ADAM_HYPER_FLOATS, NGAN_ERR_ARG, "linear_wgrad_adam: hyper holds %d floats, this library reads %d (include/ngan.h)",
+                 n_hyper, NGAN_ADAM_HYPER_FLOATS);
     NGAN_REQUIRE(B > 0 && S > 0 && C > 0 && K > 0 && K % 16 == 0 && K <= 512, NGAN_ERR_SHAPE,
                  "linear_wgrad_adam: B=%d K=%d S=%d C=%d unsupported (K a multiple of 16, at most 512)", B, K, S, C);
     const dim3 grid(ngan::ceil_div((long)C * S, 64)), block(256);

@@ -255,6 +255,21 @@ _pool_first_allowed = _diag_env("NGAN_POOL_FIRST", "1") != "0"     # A/B switch 
 _pool_out_allowed = _diag_env("NGAN_POOL_OUT", "1") != "0"         # A/B switch: pooled side output of the producing conv
 
 
+def _pooled_side(x):
+    """The 2x2-averaged copy a producing conv kernel wrote next to its output x (`_run_conv(..., pool_out=True)`), or None.  The copy
+    travels as an attribute of the tensor OBJECT, so an op that returns a new object (contiguous(), detach(), a view) simply loses
+    it -- a pooling pass runs instead, same bits.  What must never happen is a STALE copy: it is used only if x has not been written
+    since the producer stored it (tensor version counter) and its shape is exactly the pooled shape of x."""
+    side = getattr(x, "_ngan_pooled", None)
+    if side is None:
+        return None
+    yp, version = side
+    b, h2, w2, c = x.shape
+    if version != x._version or tuple(yp.shape) != (b, h2 // 2, w2 // 2, c) or yp.dtype != x.dtype or yp.device != x.device:
+        return None
+    return yp
+
+
 def _pooled(x):
     b, h2, w2, c = x.shape
     return _resample("ngan_pool2_fwd", x, (b, h2 // 2, w2 // 2, c), b, h2 // 2, w2 // 2, c)
@@ -282,8 +297,8 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=Non
     when one was made (`_pool_first`); pool_out: the consumer of y is an avg-pooled conv -- where the kernel can, it also writes
     the 2x2 average of y, which travels with y as `y._ngan_pooled` (same bits as the pooling pass it replaces)"""
     if _pool_first(resample):
-        side = getattr(x, "_ngan_pooled", None)
-        x = side if side is not None and side.shape[1] * 2 == x.shape[1] else _pooled(x)
+        side = _pooled_side(x)
+        x = side if side is not None else _pooled(x)
         resample = RES_NONE
         if keep_pooled is not None:
             keep_pooled.append(x)
@@ -309,7 +324,7 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=Non
         yp = torch.empty((b, h // 2, w // 2, cout), device=x.device, dtype=torch.float32)
         _C.call("ngan_conv3x3_fwd_ex", x, packed, bias, y, rn, None, None, yp, b, h, w, cin, cout, resample, epilogue, 0, float(slope),
                 PIXELNORM_EPS, prec, 0)
-        y._ngan_pooled = yp
+        y._ngan_pooled = (yp, y._version)       # valid for exactly this tensor object in exactly this state: _pooled_side
         return y, rn
     _C.call("ngan_conv3x3_fwd", x, packed, bias, y, rn, b, h, w, cin, cout, resample, epilogue, 0, float(slope), PIXELNORM_EPS, prec,
             _C.CONV_SKIP_BORDER if prec == 3 else 0)
@@ -587,12 +602,15 @@ class ConvLReLUPNToImage(Function):
         npix = y.numel() // c
         ws = torch.empty(1024 * c, device=y.device, dtype=torch.float32)
         gc = torch.empty_like(y)      # ToImage backward and the LeakyReLU->PixelNorm backward in one pass over y
-        if _small_grads_in_place and _accumulates_in_place(w_img) and (c // 4) & (c // 4 - 1) == 0 and c <= 256:
+        if (_small_grads_in_place and ctx.needs_input_grad[3] and _accumulates_in_place(w_img) and (c // 4) & (c // 4 - 1) == 0
+                and c <= 256):
             _C.call("ngan_to_image_bwd_pnbwd_acc", _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, w_img.grad, ws, npix, c, 1, float(slope), 1)
             gw_img = None             # w_img.grad += ... inside the reduction
         else:
             gw_img = torch.empty_like(w_img)
             _C.call("ngan_to_image_bwd_pnbwd", _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, gw_img, ws, npix, c, 1, float(slope))
+            if not ctx.needs_input_grad[3]:
+                gw_img = None         # a frozen colour weight: computed by the fused pass, handed to nobody
         gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
         return gx, gw, gb, gw_img, None, None, None, None, None
 
@@ -802,15 +820,19 @@ class FromImage(Function):
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and _param_grads_wanted():
             bias = ctx.bias_param
             c, ncol = w.shape[0], w.shape[1]
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
             if (_small_grads_in_place and ctx.needs_input_grad[1] and _accumulates_in_place(w) and (c // 4) & (c // 4 - 1) == 0 and c <= 256
-                    and (not ctx.has_bias or (bias is not None and _accumulates_in_place(bias)))):
+                    and (not want_b or (bias is not None and _accumulates_in_place(bias)))):
+                # (a frozen bias next to a trainable weight: its sum is not formed at all -- gb pointer NULL)
                 gg = _c(g)
                 b, h, wd, _ = gg.shape
                 ws = torch.empty(1024 * c * (ncol + 1), device=gg.device, dtype=torch.float32)
-                _C.call("ngan_from_image_dw_acc", x, gg, w.grad, bias.grad if ctx.has_bias else None, ws, b, h, wd, ncol, c, int(ctx.pool), 3)
+                _C.call("ngan_from_image_dw_acc", x, gg, w.grad, bias.grad if want_b else None, ws, b, h, wd, ncol, c, int(ctx.pool), 3)
             else:
                 gw, gb = FromImageDw.apply(x, g, ctx.pool, tuple(w.shape))
-                if not ctx.has_bias:
+                if not ctx.needs_input_grad[1]:
+                    gw = None
+                if not want_b:
                     gb = None
         return gx, gw, gb, None
 
@@ -1161,13 +1183,16 @@ class FinalDot(Function):
         gw = gb = None
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and _param_grads_wanted():
             bias = ctx.bias_param
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
             if (_small_grads_in_place and ctx.needs_input_grad[1] and _accumulates_in_place(weight)
-                    and (not ctx.has_bias or (bias is not None and _accumulates_in_place(bias)))):
+                    and (not want_b or (bias is not None and _accumulates_in_place(bias)))):
                 b, hh, ww, c = y.shape
-                _C.call("ngan_final_dot_dw_acc", y, _c(go), weight.grad, bias.grad if ctx.has_bias else None, b, hh * ww, c, float(ctx.scale), 3)
+                _C.call("ngan_final_dot_dw_acc", y, _c(go), weight.grad, bias.grad if want_b else None, b, hh * ww, c, float(ctx.scale), 3)
             else:
                 gw, gb = FinalDotDw.apply(y, go, ctx.scale, tuple(weight.shape))
-                if not ctx.has_bias:
+                if not ctx.needs_input_grad[1]:
+                    gw = None
+                if not want_b:
                     gb = None
         return gy, gw, gb, None
 

@@ -119,11 +119,11 @@ class FusedAdam:
             n0 = (f.params[0].numel() + ADAM_CHUNK - 1) // ADAM_CHUNK
         n_chunks = int(f.chunk_seg.numel()) - n0
         _C.call("ngan_adam_step", f.flat, f.grad, f.exp_avg, f.exp_avg_sq, f.seg_off, f.seg_len, f.seg_active, f.seg_step,
-                len(f.params), f.chunk_seg[n0:], f.chunk_off[n0:], n_chunks, self.hyper)      # also advances every active step count
+                len(f.params), f.chunk_seg[n0:], f.chunk_off[n0:], n_chunks, self.hyper, self.hyper.numel())      # also advances every active step count
         if stem_factors is not None:
             z, gc, s2, c, scale = stem_factors
             n = f.params[0].numel()
-            _C.call("ngan_linear_wgrad_adam", z, gc, f.flat[:n], f.exp_avg[:n], f.exp_avg_sq[:n], f.seg_step[:1], self.hyper,
+            _C.call("ngan_linear_wgrad_adam", z, gc, f.flat[:n], f.exp_avg[:n], f.exp_avg_sq[:n], f.seg_step[:1], self.hyper, self.hyper.numel(),
                     z.shape[0], z.shape[1], s2, c, float(scale))
         self.repack()
 
@@ -443,7 +443,19 @@ class PGGANTrainer:
             self.stem.wgrad_fn(zs, gs, self.stem.weight.grad, zs.shape[0], zs.shape[1], s2, c, scale)
 
     def g_adam(self):
+        if self._stem_grad_skipped:
+            # the stem's .grad was neither zeroed nor written by this step's g_compute: without factors the flat Adam launch would
+            # apply whatever an older step left there
+            assert self.stem is not None and self.stem.factors is not None, \
+                "g_compute skipped the stem's gradient but no factors arrived: call _exchange(flat_g) between g_compute and g_adam"
         self.opt_g.step(self.stem.factors if self._stem_grad_skipped else None)  # train.py:385
+
+    @property
+    def stem_grad_is_current(self):
+        """False after a step that handed the stem's factors to Adam instead of storing its gradient (g_step with fused_stem): the
+        stem weight's .grad then still holds an OLDER step's values -- 16.8 M of the generator's 17.1 M gradient elements.  Gradient
+        norms, clipping or logging helpers must call materialize_stem_grad() first (or check this flag)."""
+        return not self._stem_grad_skipped
 
     def g_step(self, real, z=None):
         stats = self.g_compute(real, z, skip_stem_grad=True)
@@ -569,7 +581,10 @@ class PGGANTrainer:
         # ran during THIS capture; another shape's capture overwrites stem.captured, and the eager `finish()` between replayed
         # segments must read this graph's factors, not the most recent capture's); (b) the device re-pack tables whose pointers
         # are baked into the captured Adam segments (ops drops its own references when a later capture registers new copies).
-        entry = (graphs, static_real, stats, self.stem.captured if self.stem is not None else None, ops.table_tensors())
+        # ... and (c) the two flags `_exchange` / `g_adam` read between replayed segments, as THIS capture's g_compute left them (an eager
+        # g_compute in between -- a parity test, a gradient inspection -- may have set them differently)
+        entry = (graphs, static_real, stats, self.stem.captured if self.stem is not None else None, ops.table_tensors(),
+                 (self._stem_grad_skipped, self._stem_sink_active))
         self._graph, self._entry = graphs, entry
         self._graphs[tuple(real_example.shape)] = entry
         return graphs
@@ -614,9 +629,10 @@ class PGGANTrainer:
             if self._graph is None:
                 raise RuntimeError("call capture() first (and again after every growth event)")
             entry = self._entry
-        graphs, _, stats, stem_factors, _ = entry
+        graphs, _, stats, stem_factors, _, stem_flags = entry
         if self.stem is not None:
             self.stem.captured = stem_factors     # the factors THESE graphs fill (see capture())
+        self._stem_grad_skipped, self._stem_sink_active = stem_flags
         if len(graphs) == 1:
             graphs[0].replay()
         else:

@@ -504,7 +504,7 @@ def test_stem_adam_epilogue_against_torch_adam(ngan, B, K, S2, C, gscale):
         ref.grad = scale * gscale * torch.einsum("bpc,bk->cpk", gc.double(), z.double()).reshape(rows, K)
         opt.step()
         step += 1                                        # ngan_adam_step's advance launch does this for every active tensor
-        C_.call("ngan_linear_wgrad_adam", z.to(DEV), gc.to(DEV), p, m, v, step, hyper, B, K, S2, C, scale)
+        C_.call("ngan_linear_wgrad_adam", z.to(DEV), gc.to(DEV), p, m, v, step, hyper, hyper.numel(), B, K, S2, C, scale)
         # a step moves every element by ~lr * g / |g|.  Where the fp32 and the fp64 gradient agree to 1e-7 of the tensor's scale the
         # two updates agree to ~1e-9 (measured); an element whose gradient is itself ~1e-7 of that scale may move by up to lr the
         # other way (measured: a few dozen of 16.8 M, worst 4e-5 = 0.04 lr): bound their share and the mean

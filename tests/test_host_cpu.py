@@ -46,13 +46,17 @@ def test_in_place_entry_points_validate_on_the_host(built):
     assert lib.ngan_channel_sum_acc(None, None, None, 16, 16, 1.0, 1, None) < 0
     assert lib.ngan_final_dot_dw_acc(None, None, None, None, 1, 16, 16, 1.0, 3, None) < 0
     assert lib.ngan_from_image_dw_acc(None, None, None, None, None, 1, 8, 8, 1, 16, 0, 3, None) < 0
-    assert lib.ngan_linear_wgrad_adam(None, None, None, None, None, None, None, 16, 512, 256, 128, 1.0, None) < 0
+    assert lib.ngan_linear_wgrad_adam(None, None, None, None, None, None, None, 9, 16, 512, 256, 128, 1.0, None) < 0
     assert b"null" in lib.ngan_last_error()
     # a contraction the MFMA form does not take (K must be a multiple of 16, at most 512): refused, not mis-launched
     import ctypes
     one = ctypes.c_void_p(16)        # any non-null address: the shape check comes before the launch
-    assert lib.ngan_linear_wgrad_adam(one, one, one, one, one, one, one, 16, 520, 256, 128, 1.0, None) < 0
+    assert lib.ngan_linear_wgrad_adam(one, one, one, one, one, one, one, 9, 16, 520, 256, 128, 1.0, None) < 0
     assert b"K=520" in lib.ngan_last_error()
+    # a binding written against the 5-float `hyper` of round 2 is refused by the count, not left to read past its buffer
+    assert lib.ngan_linear_wgrad_adam(one, one, one, one, one, one, one, 5, 16, 512, 256, 128, 1.0, None) == -1
+    assert lib.ngan_adam_step(one, one, one, one, one, one, one, one, 1, one, one, 1, one, 5, None) == -1
+    assert b"hyper holds 5 floats" in lib.ngan_last_error()
 
 
 def test_wide_layers_are_cut_into_kernel_sized_chunks(ngan):
