@@ -14,7 +14,16 @@ pair instead of 36, i.e. NOT the same products as the direct form; every such ke
 the fraction of its algorithmic flops it actually executes on the matrix pipe (`executed_mfma_frac`).  The faster split-bf16
 convolution mode (3 bf16 MFMAs per fp32 product group, 16-bit-mantissa operands) is timed by the same protocol right afterwards
 and reported as the labelled sub-record `"bf16x3"` of the same JSON line, with the relative error it shows against the fp32 mode
-on identical weights and draws (`max_rel_err`).  It is never the headline.
+on identical weights and draws (`max_rel_err`).  It is never the headline.  A second sub-record, `"bf16"`, is BASELINE.json's C2
+arithmetic at this workload: bf16 activation storage and conv operands (one bf16 MFMA per product group), fp32 accumulation /
+statistics / master weights -- HBM-bound, so its roofline is bytes (E x 2) against 8 TB/s; it has its own, looser tolerance
+(tests/test_gpu_bf16.py) and is never the headline either.
+
+Reading `roofline.frac` of a Winograd instance: `achieved` divides the layer's ALGORITHMIC flops (2*9*K*N per output pixel, SURVEY.md
+8d) by the launch time, and the F(2x2, 3x3) form executes only 4/9 of those multiply-adds on the matrix pipe -- so the fraction can
+legitimately exceed 1.0 (it has, in isolation: 1.03 for 32 -> 32 at 128x128).  It says how the layer's WORK relates to the roof, not
+how busy the pipe is.  For pipe occupancy read `executed_mfma_frac` (= frac x 4/9), and for the other roof `gbs / 8000`
+(`conv_family.instances[*].hbm_frac`): a Winograd instance is "at its roof" when either of those two is near 1, not when `frac` is.
 
 Rank 0 prints ONE JSON line: images/s over all ranks, plus
   roofline     -- the dominant kernel = the conv template instance (forward / input-gradient / weight-gradient entry points) with the
@@ -99,21 +108,23 @@ class ConvProbe:
 
     @staticmethod
     def wants(name, args):
-        return name in ("ngan_conv3x3_fwd", "ngan_conv3x3_fwd_ex", "ngan_conv3x3_wgrad")
+        return name in ("ngan_conv3x3_fwd", "ngan_conv3x3_fwd_ex", "ngan_conv3x3_wgrad", "ngan_bf16_conv3x3_fwd", "ngan_bf16_conv3x3_wgrad")
 
     def add(self, name, args, e0, e1):
-        if name == "ngan_conv3x3_wgrad":
-            # (x, g, gw, workspace, B, H, W, Cin, Cout, resample, scale, accumulate, precision): the contraction runs over pixels;
+        bf = name.startswith("ngan_bf16_")       # bf16 activation storage: 2 bytes per activation element (norms and images stay 4)
+        esz = 2.0 if bf else 4.0
+        if name.endswith("conv3x3_wgrad"):
+            # (x, g, gw, workspace, B, H, W, Cin, Cout, resample, scale, accumulate[, precision]): the contraction runs over pixels;
             # bytes = the input read once (1/4 of the pixels behind a bilinear x2, 4x behind an avg-pool) + the output gradient
             b, h, w, cin, cout, resample = args[4:10]
-            key = self.C.conv3x3_wgrad_kernel_name(b, h, w, cin, cout, resample, args[12])
+            key = self.C.conv3x3_wgrad_kernel_name(b, h, w, cin, cout, resample, 5 if bf else args[12])
             pix = b * h * w
             src = pix * (4 if resample == 1 else 0.25 if resample == 2 else 1)
-            self.records.append((key, 2.0 * 9 * cin * cout * pix, 4.0 * (src * cin + pix * cout), e0, e1))
+            self.records.append((key, 2.0 * 9 * cin * cout * pix, esz * (src * cin + pix * cout), e0, e1))
             return
-        o = 8 if name == "ngan_conv3x3_fwd_ex" else 5          # fwd_ex carries three more pointers (include/ngan.h)
+        o = 5 if name == "ngan_conv3x3_fwd" else 8            # the _ex / bf16 forms carry three more pointers (include/ngan.h)
         b, h, w, k, n, resample, epilogue, out_mode = args[o:o + 8]
-        key = self.C.conv3x3_kernel_name(b, h, w, k, n, resample, epilogue, out_mode, args[o + 10])   # the template instance, as rocprofv3 names it
+        key = self.C.conv3x3_kernel_name(b, h, w, k, n, resample, epilogue, out_mode, 5 if bf else args[o + 10])   # the template instance, as rocprofv3 names it
         # algorithmic work of one launch: 2*9*K*N flop per output pixel; bytes = the input read once
         # (K channels per source pixel; 1/4 of the pixels for bilinear input, 4x for pooled), the output written once
         # (4x the pixels for the pool-adjoint store; not at all when the ToImage epilogue runs without a stored activation), the
@@ -123,11 +134,11 @@ class ConvProbe:
         src = pix * (4 if resample == 1 else 0.25 if resample == 2 else 1)
         opix = pix * (4 if out_mode else 1)
         y_written = args[3] is not None
-        nbytes = 4.0 * (src * k + (opix * n if y_written else 0))
+        nbytes = esz * (src * k + (opix * n if y_written else 0))
         if epilogue == 1 or (epilogue == 3 and y_written):
             nbytes += 4.0 * pix
         if epilogue == 2:
-            nbytes += 4.0 * (opix * n + opix)
+            nbytes += esz * opix * n + 4.0 * opix
         if epilogue == 3:
             nbytes += 4.0 * pix
         self.records.append((key, 2.0 * 9 * k * n * pix, nbytes, e0, e1))
@@ -147,7 +158,7 @@ class ConvProbe:
 
 def is_split_bf16_instance(name):
     """does this kernel template instance compute its products on the bf16 MFMA (HBM is then the binding roof)?"""
-    if "up2f" in name or "wgrad_bf16x3" in name:
+    if "up2f" in name or "wgrad_bf16x3" in name or "conv3x3_bf16_kernel" in name:
         return True
     # last template argument of these three: PREC
     return ("persist" in name or "tile_kernel" in name or "mid_kernel" in name) and name.rstrip(">").endswith(", 1")
@@ -451,18 +462,41 @@ def run_mode(pkg, args, precision, device, world, rank, use_dist):
                               # instances are within 20 % of each other)
                               "frac_of_fp32_mfma_peak": (tot_f / tot_s / 1e12 / PEAK_FP32_MFMA_TFLOPS) if precision == "f32" else None,
                               "instances": {k: label(k, v) for k, v in summ.items()}}
+    if args.force_dist and world == 1 and use_graph:
+        # what the data-parallel step structure costs before any inter-GPU traffic: the same K steps as ONE captured graph, no exchange
+        # (tools/segment_probe.py measured 3.3 % in round 3); printed next to the segmented time so that a first hardware scaling
+        # run can separate "three graphs + two eager collectives" from the collectives' own time
+        del trainer
+        G2, D2 = build_nets(pkg, args.res, args.alpha, device)
+        plain = pkg.train.PGGANTrainer(G2, D2, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001, device_latents=True)
+        plain.capture(pool[0], warmup=1)
+        for i in range(args.warmup):
+            plain.replay(pool[i % len(pool)])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            plain.replay(pool[i % len(pool)])
+        torch.cuda.synchronize()
+        single = (time.perf_counter() - t1) / args.steps * 1e3
+        seg = own_elapsed / args.steps * 1e3
+        out["segmentation"] = {"segmented_ms_per_step": seg, "single_graph_ms_per_step": single, "overhead_frac": seg / single - 1.0,
+                               "exchange_ms_per_step": exchange_ms,
+                               "note": "one rank, RCCL group of one: [D fwd/bwd] -> all-reduce -> [D Adam, G fwd/bwd] -> factor all-gathers + "
+                                       "tail all-reduce -> [G Adam] against the whole iteration as one graph without a process group"}
+        del plain, G2, D2
+        trainer = None
     del trainer, G, D, pool
     torch.cuda.empty_cache()
     return out
 
 
-def precision_gap(pkg, args, device):
-    """Relative error of the split-bf16 mode against the exact-fp32 mode on identical weights, reals, latents and epsilon: the three
+def precision_gap(pkg, args, device, mode="bf16x3"):
+    """Relative error of a reduced-precision mode against the exact-fp32 mode on identical weights, reals, latents and epsilon: the three
     losses, the scores, the gradient penalty and the two nets' flat gradients (relative L2) of one iteration's forward/backward passes."""
     import torch
     out = {}
     got = {}
-    for precision in ("f32", "bf16x3"):
+    for precision in ("f32", mode):
         pkg.ops.set_conv_precision(precision)
         G, D = build_nets(pkg, args.res, args.alpha, device)
         tr = pkg.train.PGGANTrainer(G, D, learning_rate=1e-4, beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001)
@@ -481,7 +515,7 @@ def precision_gap(pkg, args, device):
         torch.cuda.synchronize()
         got[precision] = ({k: float(v) for k, v in st.items()}, gd, gg)
         del tr, G, D
-    a, b = got["f32"], got["bf16x3"]
+    a, b = got["f32"], got[mode]
     for k in a[0]:
         out[k] = abs(a[0][k] - b[0][k]) / max(abs(a[0][k]), 1e-12)
     out["D_grad_rel_l2"] = float((a[1] - b[1]).norm() / a[1].norm())
@@ -511,11 +545,11 @@ def main():
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay a captured HIP graph, 0: eager, -1: auto")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
-                    help="conv arithmetic of the headline: exact fp32 MFMA (the reference's arithmetic), or split-bf16 "
-                         "(3 bf16 MFMAs per product, fp32 accumulate) where available")
-    ap.add_argument("--sub-record", type=int, default=-1, help="1: also time the split-bf16 mode and report it as the sub-record "
-                                                               "'bf16x3'; 0: do not; -1: only on one GPU")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the headline: exact fp32 MFMA (the reference's arithmetic), split-bf16 (3 bf16 MFMAs per "
+                         "product, fp32 storage and accumulate), or bf16 (bf16 activation storage, one bf16 MFMA per product)")
+    ap.add_argument("--sub-record", type=int, default=-1, help="1: also time the reduced-precision modes and report them as the labelled "
+                                                               "sub-records 'bf16x3' and 'bf16'; 0: do not; -1: only on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient exchange even with one rank (path test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="do not time the dominant kernel with HIP events")
@@ -564,11 +598,11 @@ def main():
     pkg._C.lib()
     head = run_mode(pkg, args, args.precision, device, world, rank, use_dist)
     want_sub = args.sub_record == 1 or (args.sub_record == -1 and world == 1 and not args.force_dist)
-    sub = gap = None
+    subs = {}
     if want_sub and args.precision == "f32":
-        sub = run_mode(pkg, args, "bf16x3", device, world, rank, use_dist)
-        if rank == 0:
-            gap = precision_gap(pkg, args, device)
+        for mode in ("bf16x3", "bf16"):
+            sub = run_mode(pkg, args, mode, device, world, rank, use_dist)
+            subs[mode] = (sub, precision_gap(pkg, args, device, mode) if rank == 0 else None)
         pkg.ops.set_conv_precision("f32")
 
     if rank == 0:
@@ -577,7 +611,10 @@ def main():
         value = images / head["elapsed"]
         w_alg = wm.iteration_flops(G_WIDTHS, D_WIDTHS, 16, args.res, 512, args.alpha)   # FLOP per image per iteration
         e_alg = wm.iteration_io_elements(G_WIDTHS, D_WIDTHS, 16, args.res, 512, args.alpha)
-        dtype_of = {"f32": "f32", "bf16x3": "f32 storage/accumulate; 3x3 convs on split-bf16 MFMA (bf16x3, hi+lo operands)"}
+        dtype_of = {"f32": "f32", "bf16x3": "f32 storage/accumulate; 3x3 convs on split-bf16 MFMA (bf16x3, hi+lo operands)",
+                    "bf16": "bf16 activation storage and conv operands (one bf16 MFMA per product); f32 accumulate, PixelNorm statistics, "
+                            "images, master weights, gradients of parameters, Adam"}
+        esz_of = {"f32": 4, "bf16x3": 4, "bf16": 2}
         out = {"metric": "images/sec (G+D step incl. GP) at 512x512", "value": value, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": dtype_of[args.precision], "data": "synthetic",
@@ -588,17 +625,23 @@ def main():
                           "world_size_observed": dist.get_world_size() if use_dist else 1, "backend": backend},
                "step_tflops": value * w_alg / 1e12,
                "step_frac_of_fp32_mfma_peak": (value * w_alg / 1e12 / world / PEAK_FP32_MFMA_TFLOPS) if args.precision == "f32" else None,
-               "step_algorithmic_gbs": value * e_alg * 4 / 1e9 / world,
+               "step_algorithmic_gbs": value * e_alg * esz_of[args.precision] / 1e9 / world,
                "roofline": head["roofline"], "conv_family": head["conv_family"]}
         if head.get("ranks") is not None:
             out["ranks"] = head["ranks"]
-        if sub is not None:
+        if head.get("segmentation") is not None:
+            out["segmentation"] = head["segmentation"]
+        labels = {"bf16x3": "split-bf16 convolution mode (NOT the headline: 16-bit-mantissa operands, narrower than the reference's fp32)",
+                  "bf16": "bf16 mode = BASELINE.json's C2 arithmetic at this workload (NOT the headline: bf16 activation storage and conv operands; "
+                          "its own tolerance, tests/test_gpu_bf16.py / DESIGN.md section 8; HBM-bound: bytes = E x 2)"}
+        for mode, (sub, gap) in subs.items():
             v2 = images / sub["elapsed"]
-            out["bf16x3"] = {"label": "split-bf16 convolution mode (NOT the headline: 16-bit-mantissa operands, narrower than the reference's fp32)",
-                             "value": v2, "unit": "images/s", "ms_per_step": sub["elapsed"] / args.steps * 1e3, "dtype": dtype_of["bf16x3"],
-                             "max_rel_err": gap[0], "rel_err_vs_f32": gap[1], "step_fp32_equivalent_tflops": v2 * w_alg / 1e12,
-                             "step_algorithmic_gbs": v2 * e_alg * 4 / 1e9, "step_frac_of_hbm_peak": v2 * e_alg * 4 / 1e9 / PEAK_HBM_GBS,
-                             "roofline": sub["roofline"], "conv_family": sub["conv_family"]}
+            out[mode] = {"label": labels[mode], "value": v2, "unit": "images/s", "ms_per_step": sub["elapsed"] / args.steps * 1e3,
+                         "dtype": dtype_of[mode], "max_rel_err": gap[0], "rel_err_vs_f32": gap[1],
+                         "step_fp32_equivalent_tflops": v2 * w_alg / 1e12,
+                         "step_algorithmic_gbs": v2 * e_alg * esz_of[mode] / 1e9,
+                         "step_frac_of_hbm_peak": v2 * e_alg * esz_of[mode] / 1e9 / PEAK_HBM_GBS,
+                         "roofline": sub["roofline"], "conv_family": sub["conv_family"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.res, args.alpha, batch=args.batch)
         print(json.dumps(out), flush=True)

@@ -9,7 +9,8 @@
  *
  * Conventions
  *   - every tensor is fp32, device memory, pixel-major / channels-last: (B, H, W, C) contiguous.
- *     Images with C == 1 have the same bytes as the reference's NCHW tensors.
+ *     Images with C == 1 have the same bytes as the reference's NCHW tensors.  (The last section, "bf16 activation
+ *     storage", adds entry points whose activation tensors are bf16; everything before it is the fp32 contract.)
  *   - weights keep the reference's parameter layouts (OIHW for convs, (out, in) for Linear), so
  *     state_dict tensors are passed as they are.
  *   - the caller allocates every output and workspace; the library never allocates, frees or
@@ -308,6 +309,88 @@ int ngan_first_block_dx(const float* gc, const float* tables, float* gx, int B, 
 size_t ngan_augment_workspace_bytes(int B, int P);
 int ngan_augment_batch(const float* src, const int* idx, const void* params, float* workspace, float* out,
                        int N, int B, int P, int R, int S, void* stream);
+
+/* ==== bf16 activation storage ("bf16" mode, precision code 5): BASELINE.json's C2 configuration ==================================
+ * The reference computes in the default dtype (/root/reference/train.py:136-144: fp32); this mode is an addition with its OWN,
+ * stated tolerance (~1.5e-2 on |grad D|, 1e-1 on gradients against the fp32 path) -- never the headline.
+ *
+ * What changes: every ACTIVATION tensor -- the (B,H,W,C) outputs of conv / stem / FromImage layers, LeakyReLU -> PixelNorm outputs, and
+ * the gradients w.r.t. them -- is stored as bf16 (ngan_bf16 = the raw 16 bits, round-to-nearest-even on store), and the 3x3
+ * convolutions multiply bf16 operands with ONE v_mfma_f32_16x16x32_bf16 per product group (the fp32 master weights are rounded to
+ * bf16 by the packing kernel, scale folded in first).  What does not: accumulation, PixelNorm statistics and norms (rnorm), biases,
+ * LeakyReLU / tanh, the scalar loss heads, images (C = colours: x, x_hat, G(z), dD/dx), latents, every parameter, every parameter
+ * gradient and the Adam state are fp32, and those entry points are the ones above.
+ *
+ * Each ngan_bf16_<op> below has the arguments and semantics of ngan_<op> above; the pointers typed ngan_bf16 are the activation
+ * tensors.  Channel counts: the 3x3 conv takes K, N in {16, 32, 64, 128}; the per-pixel operators take C with C/4 a power of two
+ * <= 64 (there is no wide.hip path behind them: other counts return NGAN_ERR_SHAPE).
+ *
+ * 3x3 convolution: ngan_conv3x3_algorithm(..., precision 5) answers 5 for the shapes the bf16 kernel takes (else 0: there is no
+ * fallback), ngan_conv3x3_pack_weights / _pack_many / _packed_floats / _pack_elements take precision 5 (packed = bf16 MFMA
+ * fragments), ngan_conv3x3_epilogue_fused(..., 5) answers for epilogues 2 and 3.  Resampling (avg-pool 2x2, bilinear x2) happens
+ * while the input tile is staged: fp32 blend of the bf16 sources, one rounding.  aux_in: epilogue 2 -> the producer's output (bf16);
+ * epilogue 3 -> the N colour weights (fp32).  There is no pooled side output in this mode (the consumer pools on load). */
+typedef unsigned short ngan_bf16;
+int ngan_bf16_conv3x3_fwd(const ngan_bf16* x, const float* packed, const float* bias, ngan_bf16* y, float* rnorm,
+                          const void* aux_in, const float* aux_rn, float* aux_out,
+                          int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode,
+                          float slope, float eps, void* stream);
+/* weight gradient from bf16 x and g (fp32 slabs, fp32 gw; same workspace size, plan (precision 5) and deferred reduction as the
+ * fp32 entry point: ngan_conv3x3_wgrad_workspace_bytes, ngan_conv3x3_wgrad_plan(..., 5, out5), ngan_conv3x3_wgrad_reduce_many) */
+int ngan_bf16_conv3x3_wgrad(const ngan_bf16* x, const ngan_bf16* g, float* gw, float* workspace,
+                            int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate, void* stream);
+
+int ngan_bf16_lrelu_pixelnorm_fwd(const ngan_bf16* c, const float* bias, ngan_bf16* y, float* rnorm, long npix, int C,
+                                  float slope, float eps, void* stream);
+int ngan_bf16_lrelu_pixelnorm_bwd(const ngan_bf16* gy, const float* gr, const ngan_bf16* y, const float* rnorm, ngan_bf16* gc,
+                                  long npix, int C, float slope, void* stream);
+int ngan_bf16_lrelu_pixelnorm_bwd2(const ngan_bf16* gy, const ngan_bf16* gy2, const float* gr, const ngan_bf16* y, const float* rnorm,
+                                   ngan_bf16* gc, long npix, int C, float slope, void* stream);
+int ngan_bf16_lrelu_pixelnorm_bwdbwd(const ngan_bf16* h, const ngan_bf16* gy, const ngan_bf16* y, const float* rnorm,
+                                     ngan_bf16* ggy, ngan_bf16* gy_out, float* gr_out, long npix, int C, float slope, void* stream);
+int ngan_bf16_channel_sum(const ngan_bf16* g, float* out, float* workspace, long npix, int C, float scale, void* stream);
+int ngan_bf16_channel_sum_acc(const ngan_bf16* g, float* out, float* workspace, long npix, int C, float scale, int accumulate, void* stream);
+
+int ngan_bf16_from_image_fwd(const float* x, const float* w, const float* b, ngan_bf16* y, int B, int H, int W, int Ncol, int C,
+                             int pool, void* stream);
+int ngan_bf16_from_image_dx(const ngan_bf16* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool, void* stream);
+int ngan_bf16_from_image_dw(const float* x, const ngan_bf16* g, float* gw, float* gb, float* workspace,
+                            int B, int H, int W, int Ncol, int C, int pool, void* stream);
+int ngan_bf16_from_image_dw_acc(const float* x, const ngan_bf16* g, float* gw, float* gb, float* workspace,
+                                int B, int H, int W, int Ncol, int C, int pool, int accumulate, void* stream);
+int ngan_bf16_to_image_fwd(const ngan_bf16* x, const float* w, float* t, long npix, int C, int Ncol, void* stream);
+int ngan_bf16_to_image_bwd(const float* g, const float* t, const ngan_bf16* x, const float* w, ngan_bf16* gx, float* gw,
+                           float* workspace, long npix, int C, int Ncol, void* stream);
+int ngan_bf16_to_image_bwd_pnbwd(const float* g, const float* t, const ngan_bf16* y, const float* rnorm, const float* w, ngan_bf16* gc,
+                                 float* gw, float* workspace, long npix, int C, int Ncol, float slope, void* stream);
+int ngan_bf16_to_image_bwd_pnbwd_acc(const float* g, const float* t, const ngan_bf16* y, const float* rnorm, const float* w, ngan_bf16* gc,
+                                     float* gw, float* workspace, long npix, int C, int Ncol, float slope, int accumulate, void* stream);
+
+int ngan_bf16_up2_fwd(const ngan_bf16* x, ngan_bf16* y, int B, int h, int w, int C, void* stream);
+int ngan_bf16_up2_adjoint(const ngan_bf16* gy, ngan_bf16* gx, int B, int h, int w, int C, void* stream);
+int ngan_bf16_up2_adjoint_pnbwd(const ngan_bf16* g, const ngan_bf16* yprev, const float* rnorm, ngan_bf16* out, int B, int h, int w, int C,
+                                float slope, void* stream);
+int ngan_bf16_pool2_fwd(const ngan_bf16* x, ngan_bf16* y, int B, int h, int w, int C, void* stream);
+int ngan_bf16_pool2_adjoint(const ngan_bf16* gy, ngan_bf16* gx, int B, int h, int w, int C, void* stream);
+/* the critic's fade-in mixes two FEATURE tensors (models.py:521); the generator's mixes images (models.py:350: the fp32 ngan_lerp) */
+int ngan_bf16_lerp(const ngan_bf16* a, const ngan_bf16* b, const float* alpha, ngan_bf16* out, long n, void* stream);
+int ngan_bf16_fade_bwd(const ngan_bf16* g, const float* alpha, ngan_bf16* ga, ngan_bf16* gb, long n, void* stream);
+
+/* stem and head: the contraction reads the fp32 master weight and fp32 latents (33 MFLOP per image: nothing to gain from a bf16
+ * copy of a 67 MB weight that is read once); y / gc are bf16 */
+int ngan_bf16_linear_lrelu_pn_fwd(const float* z, const float* Wt, ngan_bf16* y, float* rnorm, int B, int K, int S, int C,
+                                  float scale, float slope, float eps, void* stream);
+int ngan_bf16_linear_wgrad(const float* z, const ngan_bf16* gc, float* gW, int B, int K, int S, int C, float scale, void* stream);
+int ngan_bf16_linear_wgrad_acc(const float* z, const ngan_bf16* gc, float* gW, int B, int K, int S, int C, float scale, int accumulate,
+                               void* stream);
+int ngan_bf16_linear_wgrad_adam(const float* z, const ngan_bf16* gc, float* p, float* m, float* v, const float* seg_step,
+                                const float* hyper, int n_hyper, int B, int K, int S, int C, float scale, void* stream);
+int ngan_bf16_linear_dgrad(const ngan_bf16* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream);
+int ngan_bf16_final_dot_fwd(const ngan_bf16* y, const float* W, const float* bias, float* out, int B, int S2, int C, float scale, void* stream);
+int ngan_bf16_final_dot_dx(const float* go, const float* W, ngan_bf16* gy, int B, int S2, int C, float scale, void* stream);
+int ngan_bf16_final_dot_dw(const ngan_bf16* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, void* stream);
+int ngan_bf16_final_dot_dw_acc(const ngan_bf16* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, int accumulate,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """ctypes binding of libngan_hip.so (C ABI: include/ngan.h).
 
-There is no CPU fallback: if the shared library is missing, or a tensor is not a contiguous fp32 CUDA
-tensor, the call raises.  PyTorch is used only for device memory and the current HIP stream.
+There is no CPU fallback: if the shared library is missing, or a tensor is not a contiguous CUDA
+tensor, the call raises.  (Tensors are fp32, or -- activations in the "bf16" mode -- bf16: ops.py picks the entry point by dtype.)  PyTorch is used only for device memory and the current HIP stream.
 """
 import ctypes
 import os
@@ -68,6 +68,17 @@ SIGNATURES = {
     "ngan_first_block_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ngan_first_block_dx": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
+# "bf16 activation storage" section of include/ngan.h: ngan_bf16_<op> has the argument list of ngan_<op> (the activation pointers are
+# bf16 tensors); the two convolution entry points carry no precision / flags arguments
+for _op in ("lrelu_pixelnorm_fwd", "lrelu_pixelnorm_bwd", "lrelu_pixelnorm_bwd2", "lrelu_pixelnorm_bwdbwd", "channel_sum", "channel_sum_acc",
+            "from_image_fwd", "from_image_dx", "from_image_dw", "from_image_dw_acc", "to_image_fwd", "to_image_bwd", "to_image_bwd_pnbwd",
+            "to_image_bwd_pnbwd_acc", "up2_fwd", "up2_adjoint", "up2_adjoint_pnbwd", "pool2_fwd", "pool2_adjoint", "lerp", "fade_bwd",
+            "linear_lrelu_pn_fwd", "linear_wgrad", "linear_wgrad_acc", "linear_wgrad_adam", "linear_dgrad", "final_dot_fwd", "final_dot_dx",
+            "final_dot_dw", "final_dot_dw_acc"):
+    SIGNATURES["ngan_bf16_" + _op] = SIGNATURES["ngan_" + _op]
+SIGNATURES["ngan_bf16_conv3x3_fwd"] = [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]
+SIGNATURES["ngan_bf16_conv3x3_wgrad"] = [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]
+
 NON_STATUS = {
     "ngan_version": ([], ctypes.c_char_p),
     "ngan_last_error": ([], ctypes.c_char_p),

@@ -14,6 +14,9 @@ static bool wino_eligible(int B, int H, int W, int K, int N, int resample) {
 extern "C" int ngan_conv3x3_algorithm(int B, int H, int W, int K, int N, int resample, int precision) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     if (precision == 0) return wino_eligible(B, H, W, K, N, resample) ? 4 : 0;
+    // bf16 activation storage: one kernel family for every shape it takes (the answer 0 means "no bf16 kernel": the caller must not
+    // fall back to an fp32-storage call with bf16 pointers)
+    if (precision == 5) return ngan::conv3x3_bf16_elements(K, N) > 0 ? 5 : 0;
     if (precision != 1) return 0;
     if (up2f_eligible(B, H, W, K, N, resample)) return 3;
     if (persist_eligible(B, H, W, K, N, resample)) return 1;
@@ -36,6 +39,8 @@ extern "C" int ngan_conv3x3_pooled_output(int B, int H, int W, int K, int N, int
 
 extern "C" int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision) {
     if (epilogue == EPI_NONE || epilogue == EPI_LRELU_PN) return 1;
+    if (precision == 5)      // the bf16 kernel has every epilogue built in (ToImage: plain input, plain store)
+        return ngan::conv3x3_bf16_elements(K, N) > 0 && (epilogue == EPI_PN_BWD ? resample == 0 : (resample == 0 && out_mode == 0)) ? 1 : 0;
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const bool persist = persist_eligible(B, H, W, K, N, resample);
     if (epilogue == EPI_TO_IMAGE) return persist && resample == 0 && out_mode == 0 ? 1 : 0;
@@ -51,6 +56,7 @@ extern "C" int ngan_conv3x3_fwd_ex(const float* x, const float* packed, const fl
                                    float slope, float eps, int precision, int flags, void* stream) {
     NGAN_REQUIRE(x && packed && (y || epilogue == EPI_TO_IMAGE), NGAN_ERR_ARG, "conv3x3_fwd: null pointer");
     NGAN_REQUIRE((flags & ~NGAN_CONV_SKIP_BORDER) == 0, NGAN_ERR_ARG, "conv3x3_fwd: unknown flags 0x%x", flags);
+    NGAN_REQUIRE(precision != 5, NGAN_ERR_ARG, "conv3x3_fwd: precision 5 (bf16 activation storage) has its own entry point, ngan_bf16_conv3x3_fwd");
     NGAN_REQUIRE(precision == 0 || (precision == 4 && ngan_conv3x3_algorithm(B, H, W, K, N, resample, 0) == 4) ||
                  (precision != 4 && precision == ngan_conv3x3_algorithm(B, H, W, K, N, resample, 1)), NGAN_ERR_ARG,
                  "conv3x3_fwd: precision %d is not available for this shape (ask ngan_conv3x3_algorithm)", precision);
@@ -127,6 +133,7 @@ extern "C" int ngan_conv3x3_kernel_name(int B, int H, int W, int K, int N, int r
     NGAN_REQUIRE(N == 16 || N == 32 || N == 64 || N == 128, NGAN_ERR_SHAPE, "conv3x3_kernel_name: N=%d", N);
     const int mti = N == 16 ? 0 : N == 32 ? 1 : N == 64 ? 2 : 3;
     const int ci = pick_cfg(mti, B, H, W);
+    if (precision == 5) return ngan::conv3x3_bf16_kernel_name(B, H, W, K, N, buf, len);
     if (precision == 3)
         snprintf(buf, len, "conv3x3_up2f_kernel<%d, %d>", K / 16, epilogue);
     else if (precision == 4 && W % 32 == 0 && (K == 32 || N == 32 || (resample == NGAN_RESAMPLE_UP2 && NGAN_DIAG_FLAG("NGAN_WINOGRAD_UP2", true))))

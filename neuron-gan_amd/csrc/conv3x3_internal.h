@@ -39,6 +39,10 @@ int conv3x3_up2f_launch(const ConvArgs& a, int epilogue, hipStream_t s);        
 int conv3x3_up2_border_launch(const ConvArgs& a, int epilogue, hipStream_t s);
 int conv3x3_generic_launch(const ConvArgs& a, int resample, int epilogue, int out_mode, hipStream_t s);                             // conv3x3_generic.hip
 long conv3x3_bf16x3_elements(int K, int N);                                                                                          // conv3x3_pack.hip
+// bf16 activation storage (precision code 5): conv3x3_bf16.hip
+long conv3x3_bf16_elements(int K, int N);                   // bf16 elements of a packed weight (0: channel counts the kernel does not take)
+int conv3x3_bf16_pack_launch(const float* w, float* packed, int Cout, int Cin, int mode, float scale, hipStream_t s);
+int conv3x3_bf16_kernel_name(int B, int H, int W, int K, int N, char* buf, int len);
 }  // namespace ngan
 
 namespace {
@@ -77,6 +81,24 @@ __device__ __forceinline__ void pin_registers(f32x4& v) { asm volatile("" : "+v"
 // ... and not before `dep` has been computed (an accumulator of the last MFMA: the scheduler may not hoist the wait above the MFMAs)
 __device__ __forceinline__ void pin_registers_after(float4& v, float& dep) {
     asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dep));
+}
+
+// plain-bf16 packing: fp32 OIHW master weights * scale -> bf16, layout [step][n-tile j][lane][8]; lane l holds output channel
+// n = 16 j + (l & 15) and contraction index kk = 8 (l >> 4) + e.  K = 16: step = tap pair (kk < 16 -> tap 2 step, else 2 step + 1; tap 9 is
+// zero padding), 5 steps; K = 32 KS: step = tap * KS + ks, channel 32 ks + kk.  mode 1 (input gradient): contraction over the
+// OUTPUT channels of the layer, taps flipped.
+__device__ __forceinline__ __bf16 bf16_weight(const float* __restrict__ w, int Cout, int Cin, int mode, float scale, long idx) {
+    const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    const int NT = N / 16, KS = K / 32;
+    const int e = idx & 7, lane = (idx >> 3) & 63;
+    const long r = idx >> 9;
+    const int j = r % NT, step = r / NT;
+    const int n = j * 16 + (lane & 15), kk = 8 * (lane >> 4) + e;
+    const int tap = K == 16 ? 2 * step + (kk >> 4) : step / KS;
+    const int k = K == 16 ? (kk & 15) : (step % KS) * 32 + kk;
+    float v = 0.f;
+    if (tap < 9) v = mode == 0 ? w[((long)n * Cin + k) * 9 + tap] : w[((long)k * Cin + n) * 9 + (8 - tap)];
+    return (__bf16)(v * scale);
 }
 
 // float index of the hi half of (16-channel group g, channel quad c4) of tile pixel (ty, tx) in the split-bf16 image

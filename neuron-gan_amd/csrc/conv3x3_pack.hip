@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackEntry* __restr
     const int Cout = e.cout, Cin = e.cin, mode = e.mode;
     if (e.precision == 3) { pack_up2f_element(e.src, e.dst, Cout, Cin, e.scale, idx); return; }
     if (e.precision == 4) { e.dst[idx] = wino_weight(e.src, Cout, Cin, mode, e.scale, idx); return; }
+    if (e.precision == 5) { reinterpret_cast<__bf16*>(e.dst)[idx] = bf16_weight(e.src, Cout, Cin, mode, e.scale, idx); return; }
     const int Kreal = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
     const int K = e.precision == 2 ? 32 : Kreal;
     if (e.precision == 0) {
@@ -202,6 +203,7 @@ extern "C" long ngan_conv3x3_pack_elements(int Cout, int Cin, int mode, int prec
     if (precision == 0) return 9L * Cin * Cout;
     if (precision == 4) return 16L * Cin * Cout;
     const int K = mode == 0 ? Cin : Cout, N = mode == 0 ? Cout : Cin;
+    if (precision == 5) return ngan::conv3x3_bf16_elements(K, N);
     if (precision == 2) return K == 16 ? ngan::conv3x3_bf16x3_elements(32, N) : 0;      // K = 16 padded to 32 (mid kernel)
     if (precision == 3) return mode == 0 && ngan::conv3x3_bf16x3_elements(K, N) ? 4 * ngan::conv3x3_bf16x3_elements(K, N) + 9L * K * N : 0;   // folded bilinear
     return ngan::conv3x3_bf16x3_elements(K, N);
@@ -218,6 +220,10 @@ extern "C" long ngan_conv3x3_packed_floats(int Cout, int Cin, int precision) {
     if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
     if (precision == 0) return 9L * Cin * Cout;
     if (precision == 4) return 16L * Cin * Cout;
+    if (precision == 5) {
+        const long e0 = ngan::conv3x3_bf16_elements(Cin, Cout), e1 = ngan::conv3x3_bf16_elements(Cout, Cin);      // forward / flipped orientation
+        return ((e0 > e1 ? e0 : e1) + 1) / 2;
+    }
     if (precision == 2) {
         const long p0 = Cin == 16 ? ngan::conv3x3_bf16x3_elements(32, Cout) : 0, p1 = Cout == 16 ? ngan::conv3x3_bf16x3_elements(32, Cin) : 0;
         return ((p0 > p1 ? p0 : p1) + 1) / 2;
@@ -233,7 +239,8 @@ extern "C" int ngan_conv3x3_pack_weights(const float* w_oihw, float* packed, int
     NGAN_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_pack_weights: Cin=%d, Cout=%d must be positive multiples of 16", Cin, Cout);
     NGAN_REQUIRE(mode == 0 || mode == 1, NGAN_ERR_ARG, "conv3x3_pack_weights: mode %d", mode);
-    NGAN_REQUIRE(precision >= 0 && precision <= 4, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
+    NGAN_REQUIRE(precision >= 0 && precision <= 5, NGAN_ERR_ARG, "conv3x3_pack_weights: precision %d", precision);
+    if (precision == 5) return ngan::conv3x3_bf16_pack_launch(w_oihw, packed, Cout, Cin, mode, scale, (hipStream_t)stream);
     if (precision == 4) {
         hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(ngan::ceil_div(16L * Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream,
                            w_oihw, packed, Cout, Cin, mode, scale);

@@ -444,7 +444,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base_lo16, const __bf16*
     return r;
 }
 
-template <int COT, int CIT, int RES, int TW>
+// PLAIN = true: bf16 activation storage (precision code 5, include/ngan.h "bf16 activation storage"): x and g ARE bf16 tensors, so there
+// is one plane per operand instead of hi + lo, the staging loads are 8 bytes per 4 channels, and a product group is ONE MFMA.
+// Resampled input (avg-pool / bilinear) is blended in fp32 from the bf16 sources and rounded once, like the forward kernel's staging.
+template <int COT, int CIT, int RES, int TW, bool PLAIN = false>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
     // tile = 256 pixels: 8 x 32, or 16 x 16 for images at most 16 wide.  One k-step = 32 pixels = one tile row (TW = 32) or two
     // consecutive rows (TW = 16): the second 16-pixel half of a fragment then sits one halo row further instead of 16 pixels.
@@ -453,7 +456,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
     constexpr int WO = COT * CIT, WR = 4 / WO, NKS = 8, KPW = NKS / WR;          // k-steps per tile / per wave
     constexpr int X_HALF2 = (TW == 32 ? 16 : HALO_W) * 16;                       // bf16 offset of a fragment's second half in x
     constexpr int X_ROWS_PER_KS = TW == 32 ? 1 : 2;
-    constexpr int G_E = 2 * COT * G_PIX * 16, X_E = 2 * CIT * X_PIX * 16;        // bf16 elements
+    constexpr int NPL = PLAIN ? 1 : 2;                                           // planes per operand: hi (+ lo)
+    constexpr int ESZ = PLAIN ? 2 : 4;                                           // bytes per stored activation element
+    constexpr int G_E = NPL * COT * G_PIX * 16, X_E = NPL * CIT * X_PIX * 16;    // bf16 elements
     // bilinear input: the low-resolution source patch is staged once (fp32) and expanded LDS -> LDS, as in conv3x3_persist_kernel
     constexpr int PH = TH / 2 + 2, PW = TW / 2 + 2, NPP = PH * PW;
     constexpr int PATCH_BYTES = RES == NGAN_RESAMPLE_UP2 ? NPP * CI_S * 4 : 0;
@@ -508,49 +513,74 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         // loads through per-image buffer descriptors: 32-bit offsets, and an out-of-range offset (tile edge, conv padding, unused
         // staging slot) reads zeros -- no branch around the load and no zero-filled registers (see conv3x3_persist_kernel)
         constexpr unsigned OOB = 0xFFFFFFF0u;
-        const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g + (long)b * a.H * a.W * a.N), 0,
-                                                                                 (unsigned)(a.H * a.W * a.N) * 4u, 0x00020000);
+        // (byte addresses through char*: with PLAIN the tensors behind a.g / a.x hold 2-byte elements)
+        const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(a.g) + (long)b * a.H * a.W * a.N * ESZ), 0, (unsigned)(a.H * a.W * a.N) * ESZ, 0x00020000);
+        auto load4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> float4 {     // 4 consecutive channels at element-offset off
+            const unsigned bo = off == OOB ? OOB : off * (unsigned)ESZ;          // out of range: the descriptor's range check returns zeros
+            if constexpr (PLAIN) {
+                const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, bo, 0, 0));
+                return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+            } else {
+                return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, bo, 0, 0));
+            }
+        };
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int gy = y0 + g_r[i], gx = x0 + g_c[i];
-            const unsigned off = (gy < a.H && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.N + g_ch[i]) * 4) : OOB;
-            gst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, off, 0, 0));
+            const unsigned off = (gy < a.H && gx < a.W) ? (unsigned)((gy * a.W + gx) * a.N + g_ch[i]) : OOB;
+            gst[i] = load4(g_rsrc, off);
         }
         if (RES == NGAN_RESAMPLE_UP2) {
-            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * h * w * a.K), 0,
-                                                                                     (unsigned)(h * w * a.K) * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(a.x) + (long)b * h * w * a.K * ESZ), 0, (unsigned)(h * w * a.K) * ESZ, 0x00020000);
             const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
 #pragma unroll
             for (int i = 0; i < NXL; ++i) {
                 const int e = tid + i * 256;
                 const int pix = e / (CI_S / 4), c4 = e % (CI_S / 4);
                 const int ly = min(max(ly0 + pix / PW, 0), h - 1), lx = min(max(lx0 + pix % PW, 0), w - 1);
-                const unsigned off = e < NPI ? (unsigned)(((ly * w + lx) * a.K + ci0 + c4 * 4) * 4) : OOB;
-                xst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+                const unsigned off = e < NPI ? (unsigned)((ly * w + lx) * a.K + ci0 + c4 * 4) : OOB;
+                xst[i] = load4(x_rsrc, off);
             }
         } else if (RES == NGAN_RESAMPLE_NONE) {
-            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.H * a.W * a.K), 0,
-                                                                                     (unsigned)(a.H * a.W * a.K) * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(a.x) + (long)b * a.H * a.W * a.K * ESZ), 0, (unsigned)(a.H * a.W * a.K) * ESZ, 0x00020000);
 #pragma unroll
             for (int i = 0; i < NXL; ++i) {
                 const int gy = y0 + x_r[i], gx = x0 + x_c[i];        // x_r = -1000 marks an unused slot: fails the range test
                 const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.K + x_ch[i]) * 4) : OOB;
-                xst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+                const unsigned off = ok ? (unsigned)((gy * a.W + gx) * a.K + x_ch[i]) : OOB;
+                xst[i] = load4(x_rsrc, off);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NXL; ++i)
-                xst[i] = x_r[i] > -1000 ? load_resampled<RES>(a.x, b, y0 + x_r[i], x0 + x_c[i], x_ch[i], a.H, a.W, a.K) : f4zero();
+            for (int i = 0; i < NXL; ++i) {
+                if constexpr (PLAIN) {     // avg-pooled input: the 2x2 mean of the bf16 source, associated like ngan_pool2_fwd
+                    const int gy = y0 + x_r[i], gx = x0 + x_c[i];
+                    float4 v = f4zero();
+                    if (x_r[i] > -1000 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+                        const long W2 = 2L * a.W;
+                        const __bf16* sp = reinterpret_cast<const __bf16*>(a.x) + (((long)b * 2 * a.H + 2 * gy) * W2 + 2 * gx) * a.K + x_ch[i];
+                        const float4 p00 = lda4(sp), p01 = lda4(sp + a.K), p10 = lda4(sp + W2 * a.K), p11 = lda4(sp + W2 * a.K + a.K);
+                        v = f4scale(f4add(f4add(p00, p01), f4add(p10, p11)), 0.25f);
+                    }
+                    xst[i] = v;
+                } else {
+                    xst[i] = x_r[i] > -1000 ? load_resampled<RES>(a.x, b, y0 + x_r[i], x0 + x_c[i], x_ch[i], a.H, a.W, a.K) : f4zero();
+                }
+            }
         }
     };
     auto split_store = [&](__bf16* img, int idx, int lo_off, float4 v) {
         bf16x4 hi, lo;
         hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-        lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-        lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
         *reinterpret_cast<bf16x4*>(img + idx) = hi;
-        *reinterpret_cast<bf16x4*>(img + idx + lo_off) = lo;
+        if constexpr (!PLAIN) {
+            lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+            lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+            *reinterpret_cast<bf16x4*>(img + idx + lo_off) = lo;
+        }
     };
 
     int tile = blockIdx.x;
@@ -600,15 +630,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         for (int kk = 0; kk < KPW; ++kk) {
             const int ks = wr * KPW + kk;
             const bf16x8 ah = tr_frag(gh + ks * 32 * 16, gh + (ks * 32 + 16) * 16);
-            const bf16x8 al = tr_frag(gl + ks * 32 * 16, gl + (ks * 32 + 16) * 16);
+            bf16x8 al;
+            if constexpr (!PLAIN) al = tr_frag(gl + ks * 32 * 16, gl + (ks * 32 + 16) * 16);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap % 3;
                 const int xo = ((ks * X_ROWS_PER_KS + dy) * HALO_W + dx) * 16;
                 const bf16x8 bh = tr_frag(xh + xo, xh + xo + X_HALF2);
-                const bf16x8 bl = tr_frag(xl + xo, xl + xo + X_HALF2);
-                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[tap], 0, 0, 0);
+                if constexpr (!PLAIN) {
+                    const bf16x8 bl = tr_frag(xl + xo, xl + xo + X_HALF2);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[tap], 0, 0, 0);
+                }
                 acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[tap], 0, 0, 0);
             }
         }
@@ -705,6 +738,18 @@ inline bool wgrad_wino_on() { return NGAN_DIAG_FLAG("NGAN_WINOGRAD_WGRAD", true)
 template <int COT, int CIT>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision, hipStream_t s) {
     dim3 grid(p.nwx, p.nslices);
+    if (precision == 5) {       // bf16 activation storage: x and g are bf16 tensors (ngan_bf16_conv3x3_wgrad)
+        if (p.tw == 32) {
+            if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32, true>), grid, dim3(256), 0, s, a);
+            else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1, 32, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2, 32, true>), grid, dim3(256), 0, s, a);
+        } else {
+            if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 16, true>), grid, dim3(256), 0, s, a);
+            else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1, 16, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2, 16, true>), grid, dim3(256), 0, s, a);
+        }
+        return ngan::launch_status("ngan_bf16_conv3x3_wgrad");
+    }
     if (precision == 1 && p.tw == 32) {
         if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32>), grid, dim3(256), 0, s, a);
         else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1, 32>), grid, dim3(256), 0, s, a);
@@ -754,6 +799,7 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
                  "conv3x3_wgrad_kernel_name: bad shape");
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
     if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
+    else if (precision == 5) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d, true>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
     else {
         const bool wino = wgrad_wino_on() && (p.tw == 32 || NGAN_WGRAD_WINO16);
         snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw,
@@ -884,9 +930,9 @@ extern "C" int ngan_conv3x3_wgrad_reduce_many(const void* entries, int n, void* 
     return NGAN_OK;
 }
 
-extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
-                                  int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate,
-                                  int precision, void* stream) {
+static int wgrad_entry(const float* x, const float* g, float* gw, float* workspace,
+                       int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate,
+                       int precision, void* stream) {
     // accumulate == 2: write the slabs only; the caller reduces them later with ngan_conv3x3_wgrad_reduce_many
     NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "conv3x3_wgrad: null pointer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0, NGAN_ERR_SHAPE, "conv3x3_wgrad: bad dims B=%d H=%d W=%d", B, H, W);
@@ -899,7 +945,7 @@ extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, flo
     WgradArgs a{x, g, workspace, B, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.n_tiles, p.n_ci_slices};
     hipStream_t s = (hipStream_t)stream;
     int st;
-    NGAN_REQUIRE(precision == 0 || precision == 1, NGAN_ERR_ARG, "conv3x3_wgrad: precision %d", precision);
+    NGAN_REQUIRE(precision == 0 || precision == 1 || precision == 5, NGAN_ERR_ARG, "conv3x3_wgrad: precision %d", precision);
     NGAN_REQUIRE(precision == 0 || (long)H * W * (Cin > Cout ? Cin : Cout) * 16 < (1L << 32), NGAN_ERR_SHAPE,
                  "conv3x3_wgrad: one image must stay below 1 GiB (H=%d W=%d): the split-bf16 kernel uses 32-bit byte offsets", H, W);
     if (p.co_s == 32 && p.ci_s == 32) st = launch_wgrad<2, 2>(a, p, resample, precision, s);
@@ -913,3 +959,17 @@ extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, flo
     return ngan::launch_status("ngan_conv3x3_wgrad(reduce)");
 }
 
+
+extern "C" int ngan_conv3x3_wgrad(const float* x, const float* g, float* gw, float* workspace,
+                                  int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate,
+                                  int precision, void* stream) {
+    NGAN_REQUIRE(precision != 5, NGAN_ERR_ARG, "conv3x3_wgrad: precision 5 (bf16 activation storage) has its own entry point, ngan_bf16_conv3x3_wgrad");
+    return wgrad_entry(x, g, gw, workspace, B, H, W, Cin, Cout, resample, scale, accumulate, precision, stream);
+}
+
+// x and g are bf16 tensors; slabs, gw and the reduction are fp32 (include/ngan.h, "bf16 activation storage")
+extern "C" int ngan_bf16_conv3x3_wgrad(const ngan_bf16* x, const ngan_bf16* g, float* gw, float* workspace,
+                                       int B, int H, int W, int Cin, int Cout, int resample, float scale, int accumulate, void* stream) {
+    return wgrad_entry(reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(g), gw, workspace, B, H, W, Cin, Cout, resample, scale,
+                       accumulate, 5, stream);
+}

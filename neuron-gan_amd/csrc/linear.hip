@@ -14,8 +14,9 @@ constexpr int BCH = 16;  // batch rows handled per block
 // straight into registers, 16 B per lane; the k-order inside a 16-wide group is permuted identically on both operands).
 // The accumulator holds sample 4q+r of weight row (channel) l & 15; LeakyReLU + PixelNorm over the C channels of the
 // pixel then go through LDS.
+template <typename T>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ z, const float* __restrict__ Wt,
-                                                         float* __restrict__ y, float* __restrict__ rn, int B, int K,
+                                                         T* __restrict__ y, float* __restrict__ rn, int B, int K,
                                                          int S, int C, float scale, float slope, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // rows of K + 4 floats: the 16 lanes of a ds_read_b128 phase read 16 different samples at the same k, and a pitch of
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     __syncthreads();
     for (int bb = tid >> 4; bb < nb; bb += 16) {
         const float inv = 1.0f / r_l[bb];
-        for (int c = tid & 15; c < C; c += 16) y[((long)(b0 + bb) * S + p) * C + c] = out_l[bb * CP + c] * inv;
+        for (int c = tid & 15; c < C; c += 16) sta1(y + ((long)(b0 + bb) * S + p) * C + c, out_l[bb * CP + c] * inv);
     }
 }
 
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 // for all of its lanes (one broadcast load) and a row costs WB x 4 FMAs per lane and one 16-byte store.
 constexpr int WB = 16;
 
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ z, const float* __restrict__ gc,
+template <typename T>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ z, const T* __restrict__ gc,
                                                            float* __restrict__ gW, int B, int K, int S, int C, float scale,
                                                            int rows_per_block) {
     const int K4 = K >> 2;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
             float4 acc = f4zero();
 #pragma unroll
             for (int i = 0; i < WB; ++i) {
-                const float gv = (b0 + i < B) ? gc[((long)(b0 + i) * S + p) * C + c] : 0.f;     // wave-uniform address
+                const float gv = (b0 + i < B) ? lda1(gc + ((long)(b0 + i) * S + p) * C + c) : 0.f;     // wave-uniform address
                 acc = f4fma(zr[i], gv, acc);
             }
             if (act) {
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 // the tensor's slices of the flat buffers; step / hyper as in ngan_adam_step).  The stem holds 16.8 M of the generator's 17.1 M
 // parameters: the stored form costs a 67 MB zero fill, a 67 MB read-modify-write here and a 67 MB read in the Adam kernel.
 struct StemAdam { float* p; float* m; float* v; const float* hyper; const float* step; };
-template <int NT, bool ADAM = false>
-__global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __restrict__ z, const float* __restrict__ gc,
+template <typename T, int NT, bool ADAM = false>
+__global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __restrict__ z, const T* __restrict__ gc,
                                                                 float* __restrict__ gW, int B, int K, int S, int C, float scale,
                                                                 int accumulate, StemAdam ad = StemAdam{}) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __r
     for (int b0 = 0; b0 < B; b0 += 4) {
         const int b = b0 + kq;
         const bool bok = b < B;
-        const float gv = (rok && bok) ? gc[((long)b * S + p) * C + c] : 0.f;
+        const float gv = (rok && bok) ? lda1(gc + ((long)b * S + p) * C + c) : 0.f;
         const float* zr = z + (long)(bok ? b : 0) * K + m;
         float zv[NT];
 #pragma unroll
@@ -196,14 +198,15 @@ __global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __r
 }
 
 // gz[b][k] = scale * sum_j gc[b][j'] * W[j][k]; one block per (b, 256-wide k slab)
-__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ gc, const float* __restrict__ Wt,
+template <typename T>
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const T* __restrict__ gc, const float* __restrict__ Wt,
                                                            float* __restrict__ gz, int B, int K, int S, int C, float scale) {
     const int b = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
     float acc = 0.f;
     for (int c = 0; c < C; ++c)
-        for (int p = 0; p < S; ++p) acc = fmaf(gc[((long)b * S + p) * C + c], Wt[((long)c * S + p) * K + k], acc);
+        for (int p = 0; p < S; ++p) acc = fmaf(lda1(gc + ((long)b * S + p) * C + c), Wt[((long)c * S + p) * K + k], acc);
     gz[(long)b * K + k] = acc * scale;
 }
 
@@ -211,7 +214,8 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
 // One block per sample.  y is (S2, C) channels-last, W is (C, S2): the block first copies W into LDS transposed ([p][c], pitch
 // C + 1) with coalesced global reads, then both operands of the dot product are contiguous.  (Gathering W with stride S2 per
 // lane instead costs one cache line per lane per load: 23 us for a 2 MB input.)
-__global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const float* __restrict__ y, const float* __restrict__ W,
+template <typename T>
+__global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const T* __restrict__ y, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              int S2, int C, float scale, int use_lds, int lg_s2, int lg_c) {
     // lg_s2 / lg_c: log2 of S2 / C when they are powers of two (the usual 16 x 16 x 128 head), else -1.  With 16 - 32 blocks in
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const float* __rest
     __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = S2 * C;
-    const float* yb = y + (long)b * n;
+    const T* yb = y + (long)b * n;
     float s = 0.f;
     if (use_lds) {
         const int CP = C + 1;
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const float* __rest
         constexpr int PRE = 32;
         float yv[PRE];
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) yv[u] = tid + u * 1024 < n ? yb[tid + u * 1024] : 0.f;
+        for (int u = 0; u < PRE; ++u) yv[u] = tid + u * 1024 < n ? lda1(yb + tid + u * 1024) : 0.f;
         if ((S2 & 3) == 0) {       // four positions of one channel per 16-byte load
             for (int e = tid * 4; e < n; e += 4096) {
                 const int c = lg_s2 >= 0 ? e >> lg_s2 : e / S2, p = e - c * S2;
@@ -254,13 +258,13 @@ __global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const float* __rest
         }
         for (int e = tid + PRE * 1024; e < n; e += 1024) {
             const int p0 = e / C, c0 = e - p0 * C;
-            a[0] = fmaf(yb[e], wt[p0 * CP + c0], a[0]);
+            a[0] = fmaf(lda1(yb + e), wt[p0 * CP + c0], a[0]);
         }
         s = (a[0] + a[1]) + (a[2] + a[3]);
     } else {
         for (int e = tid; e < n; e += 1024) {
             const int p = e / C, c = e - p * C;
-            s = fmaf(yb[e], W[(long)c * S2 + p], s);
+            s = fmaf(lda1(yb + e), W[(long)c * S2 + p], s);
         }
     }
     s = group_sum<64>(s);
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(1024) void final_dot_fwd_kernel(const float* __rest
     }
 }
 
-__global__ void final_dot_dx_kernel(const float* __restrict__ go, const float* __restrict__ W, float* __restrict__ gy,
+template <typename T>
+__global__ void final_dot_dx_kernel(const float* __restrict__ go, const float* __restrict__ W, T* __restrict__ gy,
                                     int B, int S2, int C, float scale) {
     const long n = (long)S2 * C, total = (long)B * n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -282,11 +287,12 @@ __global__ void final_dot_dx_kernel(const float* __restrict__ go, const float* _
         const long e = i - (long)b * n;
         const int c = (int)(e % C);
         const int p = (int)(e / C);
-        gy[i] = scale * go[b] * W[(long)c * S2 + p];
+        sta1(gy + i, scale * go[b] * W[(long)c * S2 + p]);
     }
 }
 
-__global__ void final_dot_dw_kernel(const float* __restrict__ y, const float* __restrict__ go, float* __restrict__ gW,
+template <typename T>
+__global__ void final_dot_dw_kernel(const T* __restrict__ y, const float* __restrict__ go, float* __restrict__ gW,
                                     float* __restrict__ gb, int B, int S2, int C, float scale, int accumulate) {
     const long n = (long)S2 * C;                          // accumulate: bit 0 gW += , bit 1 gb +=
     // a thread per element of y's (p, c) order: the B reads of a wave are contiguous (the gradient's own (c, p) order made every
@@ -297,10 +303,10 @@ __global__ void final_dot_dw_kernel(const float* __restrict__ y, const float* __
         float s0 = 0.f, s1 = 0.f;
         int b = 0;
         for (; b + 1 < B; b += 2) {
-            s0 = fmaf(go[b], y[(long)b * n + i], s0);
-            s1 = fmaf(go[b + 1], y[(long)(b + 1) * n + i], s1);
+            s0 = fmaf(go[b], lda1(y + (long)b * n + i), s0);
+            s1 = fmaf(go[b + 1], lda1(y + (long)(b + 1) * n + i), s1);
         }
-        if (b < B) s0 = fmaf(go[b], y[(long)b * n + i], s0);
+        if (b < B) s0 = fmaf(go[b], lda1(y + (long)b * n + i), s0);
         const float s = s0 + s1;
         float* o = gW + (long)c * S2 + p;
         *o = (accumulate & 1) ? *o + s * scale : s * scale;
@@ -319,8 +325,14 @@ int ew_blocks(long n) {
 
 }  // namespace
 
-extern "C" int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* y, float* rnorm, int B, int K, int S, int C,
-                                        float scale, float slope, float eps, void* stream) {
+#define BF(p) reinterpret_cast<const __bf16*>(p)
+#define BFM(p) reinterpret_cast<__bf16*>(p)
+
+// T: storage type of the activation operand (y / gc): float, or __bf16 for the "bf16 activation storage" entry points.  z, the
+// weight and everything derived from them stay fp32.
+template <typename T>
+static int linear_fwd_impl(const float* z, const float* Wt, T* y, float* rnorm, int B, int K, int S, int C, float scale, float slope, float eps,
+                           void* stream) {
     NGAN_REQUIRE(z && Wt && y && rnorm, NGAN_ERR_ARG, "linear_lrelu_pn_fwd: null pointer");
     NGAN_REQUIRE(B > 0 && K > 0 && K % 16 == 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: B=%d K=%d (multiple of 16) S=%d C=%d unsupported",
                  B, K, S, C);
@@ -328,23 +340,24 @@ extern "C" int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* 
     const size_t lds = (size_t)(BCH * (K + 4) + BCH * (C + 4) + BCH) * sizeof(float);
     NGAN_REQUIRE(lds <= 160 * 1024, NGAN_ERR_SHAPE, "linear_lrelu_pn_fwd: K=%d C=%d need %zu B of LDS", K, C, lds);
     if (lds > 64 * 1024) {      // wide stems (the 1024-channel presets): more than the default dynamic-LDS limit of a launch
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NGAN_REQUIRE(e == hipSuccess, (int)e, "linear_lrelu_pn_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(S, ngan::ceil_div(B, BCH)), dim3(256), lds, (hipStream_t)stream, z, Wt, y, rnorm,
+    hipLaunchKernelGGL(linear_fwd_kernel<T>, dim3(S, ngan::ceil_div(B, BCH)), dim3(256), lds, (hipStream_t)stream, z, Wt, y, rnorm,
                        B, K, S, C, scale, slope, eps);
     return ngan::launch_status("ngan_linear_lrelu_pn_fwd");
 }
-
-extern "C" int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale,
-                                     int accumulate, void* stream);
-
-extern "C" int ngan_linear_wgrad(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale, void* stream) {
-    return ngan_linear_wgrad_acc(z, gc, gW, B, K, S, C, scale, 0, stream);
+extern "C" int ngan_linear_lrelu_pn_fwd(const float* z, const float* Wt, float* y, float* rnorm, int B, int K, int S, int C,
+                                        float scale, float slope, float eps, void* stream) {
+    return linear_fwd_impl<float>(z, Wt, y, rnorm, B, K, S, C, scale, slope, eps, stream);
+}
+extern "C" int ngan_bf16_linear_lrelu_pn_fwd(const float* z, const float* Wt, ngan_bf16* y, float* rnorm, int B, int K, int S, int C,
+                                             float scale, float slope, float eps, void* stream) {
+    return linear_fwd_impl<__bf16>(z, Wt, BFM(y), rnorm, B, K, S, C, scale, slope, eps, stream);
 }
 
-extern "C" int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale,
-                                     int accumulate, void* stream) {
+template <typename T>
+static int linear_wgrad_impl(const float* z, const T* gc, float* gW, int B, int K, int S, int C, float scale, int accumulate, void* stream) {
     NGAN_REQUIRE(z && gc && gW, NGAN_ERR_ARG, "linear_wgrad: null pointer");
     NGAN_REQUIRE(!accumulate || (K % 16 == 0 && K <= 512), NGAN_ERR_SHAPE, "linear_wgrad: accumulate needs K <= 512, a multiple of 16 (K=%d)", K);
     NGAN_REQUIRE(B > 0 && K > 0 && K % 4 == 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_wgrad: B=%d K=%d S=%d C=%d unsupported", B, K, S, C);
@@ -352,18 +365,33 @@ extern "C" int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW,
     const long rows = (long)C * S;
     if (K % 16 == 0 && K <= 512) {
         const dim3 grid(ngan::ceil_div(rows, 64)), block(256);
-        if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<8, false>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate, StemAdam{});
-        else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<32, false>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate, StemAdam{});
+        if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<T, 8, false>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate, StemAdam{});
+        else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<T, 32, false>), grid, block, 0, (hipStream_t)stream, z, gc, gW, B, K, S, C, scale, accumulate, StemAdam{});
         return ngan::launch_status("ngan_linear_wgrad(mfma)");
     }
     const int rpb = rows >= 4096 ? 16 : 4;
-    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(ngan::ceil_div(rows, rpb)), dim3(256), 0, (hipStream_t)stream, z, gc, gW,
+    hipLaunchKernelGGL(linear_wgrad_kernel<T>, dim3(ngan::ceil_div(rows, rpb)), dim3(256), 0, (hipStream_t)stream, z, gc, gW,
                        B, K, S, C, scale, rpb);
     return ngan::launch_status("ngan_linear_wgrad");
 }
+extern "C" int ngan_linear_wgrad_acc(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale,
+                                     int accumulate, void* stream) {
+    return linear_wgrad_impl<float>(z, gc, gW, B, K, S, C, scale, accumulate, stream);
+}
+extern "C" int ngan_linear_wgrad(const float* z, const float* gc, float* gW, int B, int K, int S, int C, float scale, void* stream) {
+    return linear_wgrad_impl<float>(z, gc, gW, B, K, S, C, scale, 0, stream);
+}
+extern "C" int ngan_bf16_linear_wgrad_acc(const float* z, const ngan_bf16* gc, float* gW, int B, int K, int S, int C, float scale,
+                                          int accumulate, void* stream) {
+    return linear_wgrad_impl<__bf16>(z, BF(gc), gW, B, K, S, C, scale, accumulate, stream);
+}
+extern "C" int ngan_bf16_linear_wgrad(const float* z, const ngan_bf16* gc, float* gW, int B, int K, int S, int C, float scale, void* stream) {
+    return linear_wgrad_impl<__bf16>(z, BF(gc), gW, B, K, S, C, scale, 0, stream);
+}
 
-extern "C" int ngan_linear_wgrad_adam(const float* z, const float* gc, float* p, float* m, float* v, const float* seg_step,
-                                      const float* hyper, int n_hyper, int B, int K, int S, int C, float scale, void* stream) {
+template <typename T>
+static int linear_wgrad_adam_impl(const float* z, const T* gc, float* p, float* m, float* v, const float* seg_step,
+                                  const float* hyper, int n_hyper, int B, int K, int S, int C, float scale, void* stream) {
     NGAN_REQUIRE(z && gc && p && m && v && seg_step && hyper, NGAN_ERR_ARG, "linear_wgrad_adam: null pointer");
     NGAN_REQUIRE(n_hyper == NGAN_ADAM_HYPER_FLOATS, NGAN_ERR_ARG, "linear_wgrad_adam: hyper holds %d floats, this library reads %d (include/ngan.h)",
                  n_hyper, NGAN_ADAM_HYPER_FLOATS);
@@ -371,48 +399,88 @@ extern "C" int ngan_linear_wgrad_adam(const float* z, const float* gc, float* p,
                  "linear_wgrad_adam: B=%d K=%d S=%d C=%d unsupported (K a multiple of 16, at most 512)", B, K, S, C);
     const dim3 grid(ngan::ceil_div((long)C * S, 64)), block(256);
     const StemAdam ad{p, m, v, hyper, seg_step};
-    if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<8, true>), grid, block, 0, (hipStream_t)stream, z, gc, nullptr, B, K, S, C, scale, 0, ad);
-    else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<32, true>), grid, block, 0, (hipStream_t)stream, z, gc, nullptr, B, K, S, C, scale, 0, ad);
+    if (K <= 128) hipLaunchKernelGGL((linear_wgrad_mfma_kernel<T, 8, true>), grid, block, 0, (hipStream_t)stream, z, gc, nullptr, B, K, S, C, scale, 0, ad);
+    else hipLaunchKernelGGL((linear_wgrad_mfma_kernel<T, 32, true>), grid, block, 0, (hipStream_t)stream, z, gc, nullptr, B, K, S, C, scale, 0, ad);
     return ngan::launch_status("ngan_linear_wgrad_adam");
 }
-
-extern "C" int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream) {
-    NGAN_REQUIRE(gc && Wt && gz, NGAN_ERR_ARG, "linear_dgrad: null pointer");
-    NGAN_REQUIRE(B > 0 && K > 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_dgrad: B=%d K=%d S=%d C=%d unsupported", B, K, S, C);
-    hipLaunchKernelGGL(linear_dgrad_kernel, dim3(ngan::ceil_div(K, 256), B), dim3(256), 0, (hipStream_t)stream, gc, Wt, gz, B, K, S, C, scale);
-    return ngan::launch_status("ngan_linear_dgrad");
+extern "C" int ngan_linear_wgrad_adam(const float* z, const float* gc, float* p, float* m, float* v, const float* seg_step,
+                                      const float* hyper, int n_hyper, int B, int K, int S, int C, float scale, void* stream) {
+    return linear_wgrad_adam_impl<float>(z, gc, p, m, v, seg_step, hyper, n_hyper, B, K, S, C, scale, stream);
+}
+extern "C" int ngan_bf16_linear_wgrad_adam(const float* z, const ngan_bf16* gc, float* p, float* m, float* v, const float* seg_step,
+                                           const float* hyper, int n_hyper, int B, int K, int S, int C, float scale, void* stream) {
+    return linear_wgrad_adam_impl<__bf16>(z, BF(gc), p, m, v, seg_step, hyper, n_hyper, B, K, S, C, scale, stream);
 }
 
-extern "C" int ngan_final_dot_fwd(const float* y, const float* W, const float* bias, float* out, int B, int S2, int C, float scale,
-                                  void* stream) {
+template <typename T>
+static int linear_dgrad_impl(const T* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream) {
+    NGAN_REQUIRE(gc && Wt && gz, NGAN_ERR_ARG, "linear_dgrad: null pointer");
+    NGAN_REQUIRE(B > 0 && K > 0 && S > 0 && C > 0, NGAN_ERR_SHAPE, "linear_dgrad: B=%d K=%d S=%d C=%d unsupported", B, K, S, C);
+    hipLaunchKernelGGL(linear_dgrad_kernel<T>, dim3(ngan::ceil_div(K, 256), B), dim3(256), 0, (hipStream_t)stream, gc, Wt, gz, B, K, S, C, scale);
+    return ngan::launch_status("ngan_linear_dgrad");
+}
+extern "C" int ngan_linear_dgrad(const float* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream) {
+    return linear_dgrad_impl<float>(gc, Wt, gz, B, K, S, C, scale, stream);
+}
+extern "C" int ngan_bf16_linear_dgrad(const ngan_bf16* gc, const float* Wt, float* gz, int B, int K, int S, int C, float scale, void* stream) {
+    return linear_dgrad_impl<__bf16>(BF(gc), Wt, gz, B, K, S, C, scale, stream);
+}
+
+template <typename T>
+static int final_dot_fwd_impl(const T* y, const float* W, const float* bias, float* out, int B, int S2, int C, float scale, void* stream) {
     NGAN_REQUIRE(y && W && out && B > 0 && S2 > 0 && C > 0, NGAN_ERR_ARG, "final_dot_fwd: bad argument");
     const size_t lds = (size_t)S2 * (C + 1) * sizeof(float);
     const int use_lds = lds <= 150 * 1024;
-    static bool attr_set = false;
+    static bool attr_set = false;          // (one flag per instantiation, i.e. per kernel)
     if (use_lds && lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(final_dot_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(final_dot_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         NGAN_REQUIRE(e == hipSuccess, (int)e, "final_dot_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
-    hipLaunchKernelGGL(final_dot_fwd_kernel, dim3(B), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, y, W, bias, out, S2, C, scale, use_lds,
+    hipLaunchKernelGGL(final_dot_fwd_kernel<T>, dim3(B), dim3(1024), use_lds ? lds : 0, (hipStream_t)stream, y, W, bias, out, S2, C, scale, use_lds,
                        lg(S2), lg(C));
     return ngan::launch_status("ngan_final_dot_fwd");
 }
+extern "C" int ngan_final_dot_fwd(const float* y, const float* W, const float* bias, float* out, int B, int S2, int C, float scale,
+                                  void* stream) {
+    return final_dot_fwd_impl<float>(y, W, bias, out, B, S2, C, scale, stream);
+}
+extern "C" int ngan_bf16_final_dot_fwd(const ngan_bf16* y, const float* W, const float* bias, float* out, int B, int S2, int C, float scale,
+                                       void* stream) {
+    return final_dot_fwd_impl<__bf16>(BF(y), W, bias, out, B, S2, C, scale, stream);
+}
 
-extern "C" int ngan_final_dot_dx(const float* go, const float* W, float* gy, int B, int S2, int C, float scale, void* stream) {
+template <typename T>
+static int final_dot_dx_impl(const float* go, const float* W, T* gy, int B, int S2, int C, float scale, void* stream) {
     NGAN_REQUIRE(go && W && gy && B > 0 && S2 > 0 && C > 0, NGAN_ERR_ARG, "final_dot_dx: bad argument");
-    hipLaunchKernelGGL(final_dot_dx_kernel, dim3(ew_blocks((long)B * S2 * C)), dim3(256), 0, (hipStream_t)stream, go, W, gy, B, S2, C, scale);
+    hipLaunchKernelGGL(final_dot_dx_kernel<T>, dim3(ew_blocks((long)B * S2 * C)), dim3(256), 0, (hipStream_t)stream, go, W, gy, B, S2, C, scale);
     return ngan::launch_status("ngan_final_dot_dx");
 }
-
-extern "C" int ngan_final_dot_dw_acc(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, int accumulate,
-                                     void* stream) {
-    NGAN_REQUIRE(y && go && gW && B > 0 && S2 > 0 && C > 0, NGAN_ERR_ARG, "final_dot_dw: bad argument");
-    hipLaunchKernelGGL(final_dot_dw_kernel, dim3(ew_blocks((long)S2 * C)), dim3(256), 0, (hipStream_t)stream, y, go, gW, gb, B, S2, C, scale, accumulate);
-    return ngan::launch_status("ngan_final_dot_dw");
+extern "C" int ngan_final_dot_dx(const float* go, const float* W, float* gy, int B, int S2, int C, float scale, void* stream) {
+    return final_dot_dx_impl<float>(go, W, gy, B, S2, C, scale, stream);
+}
+extern "C" int ngan_bf16_final_dot_dx(const float* go, const float* W, ngan_bf16* gy, int B, int S2, int C, float scale, void* stream) {
+    return final_dot_dx_impl<__bf16>(go, W, BFM(gy), B, S2, C, scale, stream);
 }
 
+template <typename T>
+static int final_dot_dw_impl(const T* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, int accumulate, void* stream) {
+    NGAN_REQUIRE(y && go && gW && B > 0 && S2 > 0 && C > 0, NGAN_ERR_ARG, "final_dot_dw: bad argument");
+    hipLaunchKernelGGL(final_dot_dw_kernel<T>, dim3(ew_blocks((long)S2 * C)), dim3(256), 0, (hipStream_t)stream, y, go, gW, gb, B, S2, C, scale, accumulate);
+    return ngan::launch_status("ngan_final_dot_dw");
+}
+extern "C" int ngan_final_dot_dw_acc(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, int accumulate,
+                                     void* stream) {
+    return final_dot_dw_impl<float>(y, go, gW, gb, B, S2, C, scale, accumulate, stream);
+}
 extern "C" int ngan_final_dot_dw(const float* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, void* stream) {
-    return ngan_final_dot_dw_acc(y, go, gW, gb, B, S2, C, scale, 0, stream);
+    return final_dot_dw_impl<float>(y, go, gW, gb, B, S2, C, scale, 0, stream);
+}
+extern "C" int ngan_bf16_final_dot_dw_acc(const ngan_bf16* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale,
+                                          int accumulate, void* stream) {
+    return final_dot_dw_impl<__bf16>(BF(y), go, gW, gb, B, S2, C, scale, accumulate, stream);
+}
+extern "C" int ngan_bf16_final_dot_dw(const ngan_bf16* y, const float* go, float* gW, float* gb, int B, int S2, int C, float scale, void* stream) {
+    return final_dot_dw_impl<__bf16>(BF(y), go, gW, gb, B, S2, C, scale, 0, stream);
 }

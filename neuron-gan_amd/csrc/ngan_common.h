@@ -77,6 +77,36 @@ __device__ __forceinline__ void adam_update(const AdamCoef& k, float g, float& p
     p -= k.step_size * (mv / (sqrtf(vv) * k.inv_sqrt_bc2 + k.eps));   // p.addcdiv_(m, sqrt(v)/sqrt(bc2) + eps, -lr/bc1)
 }
 
+// ---- activation storage type (round 4: "bf16" mode, precision code 5 of include/ngan.h) -------------------------------------------
+// Every kernel that reads or writes an ACTIVATION tensor (a conv / stem / FromImage output, or the gradient w.r.t. one) is a template
+// over its storage type T: float (the reference's arithmetic, the product default) or __bf16 (2-byte storage, round-to-nearest-even
+// on store).  Arithmetic between a load and a store is fp32 in both; byte offsets follow from sizeof(T) through the pointer type.
+// Images, norms, scalars, parameters, parameter gradients and Adam state are fp32 in both modes.
+//   lda4(p) : 4 consecutive channels at p -> float4          sta4(p, v) : float4 -> 4 consecutive channels at p
+//   lda1 / sta1 : one element
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }            // element 0 of a packed pair
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }    // element 1
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {                                     // {a, b} -> packed pair, RNE
+    const bf16x2_t r = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, r);
+}
+template <typename T> __device__ __forceinline__ float4 lda4(const T* p);
+template <> __device__ __forceinline__ float4 lda4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 lda4<__bf16>(const __bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+}
+template <typename T> __device__ __forceinline__ void sta4(T* p, float4 v);
+template <> __device__ __forceinline__ void sta4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void sta4<__bf16>(__bf16* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+}
+template <typename T> __device__ __forceinline__ float lda1(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void sta1(T* p, float v) { *p = (T)v; }
+
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4fma(float4 a, float s, float4 c) {

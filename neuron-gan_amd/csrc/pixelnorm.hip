@@ -1,4 +1,4 @@
-// LeakyReLU -> PixelNorm forward, backward and backward-of-backward on channels-last fp32 tensors.
+// LeakyReLU -> PixelNorm forward, backward and backward-of-backward on channels-last tensors (fp32, or bf16 storage: template T).
 // Replaces the ~1700 decomposed ATen elementwise dispatches per step that /root/reference/models.py:118,126
 // (PixelNorm) and models.py:263 (LeakyReLU) issue, including their first- and second-order autograd
 // (SURVEY.md 2.1, Appendix C).  HBM-bound: one pixel's C channels are C/4 consecutive lanes holding a float4
@@ -9,38 +9,38 @@ namespace {
 
 __device__ __forceinline__ float lrelu_mask(float y, float slope) { return y > 0.f ? 1.f : slope; }
 
-template <int LPP>
-__global__ __launch_bounds__(256) void pn_fwd_kernel(const float* __restrict__ c, const float* __restrict__ bias,
-                                                     float* __restrict__ y, float* __restrict__ rn, long npix, int C,
+template <typename T, int LPP>
+__global__ __launch_bounds__(256) void pn_fwd_kernel(const T* __restrict__ c, const float* __restrict__ bias,
+                                                     T* __restrict__ y, float* __restrict__ rn, long npix, int C,
                                                      float slope, float eps) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long pix = gid / LPP;
     const int sub = (int)(gid % LPP);
     const bool ok = pix < npix;
-    float4 v = ok ? ld4(c + pix * C + sub * 4) : f4zero();
+    float4 v = ok ? lda4(c + pix * C + sub * 4) : f4zero();
     if (bias) v = f4add(v, ld4(bias + sub * 4));
     v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
     v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
     const float ss = group_sum<LPP>(f4dot(v, v));
     const float r = sqrtf(ss / (float)C + eps);
     if (ok) {
-        st4(y + pix * C + sub * 4, f4scale(v, 1.0f / r));
+        sta4(y + pix * C + sub * 4, f4scale(v, 1.0f / r));
         if (sub == 0) rn[pix] = r;
     }
 }
 
-template <int LPP>
-__global__ __launch_bounds__(256) void pn_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ gr,
-                                                     const float* __restrict__ y, const float* __restrict__ rn,
-                                                     float* __restrict__ gc, long npix, int C, float slope,
-                                                     const float* __restrict__ gy2) {
+template <typename T, int LPP>
+__global__ __launch_bounds__(256) void pn_bwd_kernel(const T* __restrict__ gy, const float* __restrict__ gr,
+                                                     const T* __restrict__ y, const float* __restrict__ rn,
+                                                     T* __restrict__ gc, long npix, int C, float slope,
+                                                     const T* __restrict__ gy2) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long pix = gid / LPP;
     const int sub = (int)(gid % LPP);
     const bool ok = pix < npix;
-    float4 g = ok ? ld4(gy + pix * C + sub * 4) : f4zero();
-    if (gy2 && ok) g = f4add(g, ld4(gy2 + pix * C + sub * 4));      // a second contribution to the same gradient, summed here
-    const float4 yy = ok ? ld4(y + pix * C + sub * 4) : f4zero();
+    float4 g = ok ? lda4(gy + pix * C + sub * 4) : f4zero();
+    if (gy2 && ok) g = f4add(g, lda4(gy2 + pix * C + sub * 4));      // a second contribution to the same gradient, summed here
+    const float4 yy = ok ? lda4(y + pix * C + sub * 4) : f4zero();
     const float r = ok ? rn[pix] : 1.f;
     const float inv_c = 1.0f / (float)C;
     const float s = group_sum<LPP>(f4dot(g, yy)) * inv_c;
@@ -51,21 +51,21 @@ __global__ __launch_bounds__(256) void pn_bwd_kernel(const float* __restrict__ g
     o.y = ((g.y - yy.y * s) * inv_r + k * yy.y) * lrelu_mask(yy.y, slope);
     o.z = ((g.z - yy.z * s) * inv_r + k * yy.z) * lrelu_mask(yy.z, slope);
     o.w = ((g.w - yy.w * s) * inv_r + k * yy.w) * lrelu_mask(yy.w, slope);
-    if (ok) st4(gc + pix * C + sub * 4, o);
+    if (ok) sta4(gc + pix * C + sub * 4, o);
 }
 
-template <int LPP>
-__global__ __launch_bounds__(256) void pn_bwdbwd_kernel(const float* __restrict__ h, const float* __restrict__ gy,
-                                                        const float* __restrict__ y, const float* __restrict__ rn,
-                                                        float* __restrict__ ggy, float* __restrict__ gy_out,
+template <typename T, int LPP>
+__global__ __launch_bounds__(256) void pn_bwdbwd_kernel(const T* __restrict__ h, const T* __restrict__ gy,
+                                                        const T* __restrict__ y, const float* __restrict__ rn,
+                                                        T* __restrict__ ggy, T* __restrict__ gy_out,
                                                         float* __restrict__ gr_out, long npix, int C, float slope) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long pix = gid / LPP;
     const int sub = (int)(gid % LPP);
     const bool ok = pix < npix;
-    float4 hp = ok ? ld4(h + pix * C + sub * 4) : f4zero();
-    const float4 g = ok ? ld4(gy + pix * C + sub * 4) : f4zero();
-    const float4 yy = ok ? ld4(y + pix * C + sub * 4) : f4zero();
+    float4 hp = ok ? lda4(h + pix * C + sub * 4) : f4zero();
+    const float4 g = ok ? lda4(gy + pix * C + sub * 4) : f4zero();
+    const float4 yy = ok ? lda4(y + pix * C + sub * 4) : f4zero();
     const float r = ok ? rn[pix] : 1.f;
     hp.x *= lrelu_mask(yy.x, slope); hp.y *= lrelu_mask(yy.y, slope);
     hp.z *= lrelu_mask(yy.z, slope); hp.w *= lrelu_mask(yy.w, slope);
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void pn_bwdbwd_kernel(const float* __restrict_
         a.z = (hp.z - yy.z * t) * inv_r; a.w = (hp.w - yy.w * t) * inv_r;
         bq.x = -(s * hp.x + t * g.x) * inv_r; bq.y = -(s * hp.y + t * g.y) * inv_r;
         bq.z = -(s * hp.z + t * g.z) * inv_r; bq.w = -(s * hp.w + t * g.w) * inv_r;
-        st4(ggy + pix * C + sub * 4, a);
-        st4(gy_out + pix * C + sub * 4, bq);
+        sta4(ggy + pix * C + sub * 4, a);
+        sta4(gy_out + pix * C + sub * 4, bq);
         if (sub == 0) gr_out[pix] = -(float)C * (u - s * t) * inv_r * inv_r;
     }
 }
@@ -98,47 +98,88 @@ bool lpp_ok(int C) {
         const dim3 grid(ngan::ceil_div(npix * lpp, 256)), block(256);                                              \
         hipStream_t s_ = (hipStream_t)stream;                                                                     \
         switch (lpp) {                                                                                            \
-            case 1: hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, s_, __VA_ARGS__); break;                        \
-            case 2: hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, s_, __VA_ARGS__); break;                        \
-            case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, s_, __VA_ARGS__); break;                        \
-            case 8: hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, s_, __VA_ARGS__); break;                        \
-            case 16: hipLaunchKernelGGL((KERNEL<16>), grid, block, 0, s_, __VA_ARGS__); break;                      \
-            case 32: hipLaunchKernelGGL((KERNEL<32>), grid, block, 0, s_, __VA_ARGS__); break;                      \
-            default: hipLaunchKernelGGL((KERNEL<64>), grid, block, 0, s_, __VA_ARGS__); break;                      \
+            case 1: hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, s_, __VA_ARGS__); break;                        \
+            case 2: hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, s_, __VA_ARGS__); break;                        \
+            case 4: hipLaunchKernelGGL((KERNEL<T, 4>), grid, block, 0, s_, __VA_ARGS__); break;                        \
+            case 8: hipLaunchKernelGGL((KERNEL<T, 8>), grid, block, 0, s_, __VA_ARGS__); break;                        \
+            case 16: hipLaunchKernelGGL((KERNEL<T, 16>), grid, block, 0, s_, __VA_ARGS__); break;                      \
+            case 32: hipLaunchKernelGGL((KERNEL<T, 32>), grid, block, 0, s_, __VA_ARGS__); break;                      \
+            default: hipLaunchKernelGGL((KERNEL<T, 64>), grid, block, 0, s_, __VA_ARGS__); break;                      \
         }                                                                                                         \
     } while (0)
 
-}  // namespace
-
-extern "C" int ngan_lrelu_pixelnorm_fwd(const float* c, const float* bias, float* y, float* rnorm, long npix, int C,
-                                        float slope, float eps, void* stream) {
+// T = float: the fp32 contract of include/ngan.h, with csrc/wide.hip behind it for channel counts outside the lane-group kernels'
+// range; T = __bf16: the bf16-storage entry points (no wide path)
+template <typename T>
+int pn_fwd_impl(const T* c, const float* bias, T* y, float* rnorm, long npix, int C, float slope, float eps, void* stream) {
     NGAN_REQUIRE(c && y && rnorm, NGAN_ERR_ARG, "lrelu_pixelnorm_fwd: null pointer");
-    if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C)) return ngan::wide_pn_fwd(c, bias, y, rnorm, npix, C, slope, eps, (hipStream_t)stream);
+    if constexpr (sizeof(T) == 4)
+        if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C)) return ngan::wide_pn_fwd(c, bias, y, rnorm, npix, C, slope, eps, (hipStream_t)stream);
     NGAN_REQUIRE(npix > 0 && lpp_ok(C), NGAN_ERR_SHAPE, "lrelu_pixelnorm_fwd: npix=%ld C=%d unsupported", npix, C);
     PN_DISPATCH(pn_fwd_kernel, c, bias, y, rnorm, npix, C, slope, eps);
     return ngan::launch_status("ngan_lrelu_pixelnorm_fwd");
 }
 
-extern "C" int ngan_lrelu_pixelnorm_bwd2(const float* gy, const float* gy2, const float* gr, const float* y, const float* rnorm,
-                                         float* gc, long npix, int C, float slope, void* stream) {
+template <typename T>
+int pn_bwd2_impl(const T* gy, const T* gy2, const float* gr, const T* y, const float* rnorm, T* gc, long npix, int C, float slope, void* stream) {
     NGAN_REQUIRE(gy && y && rnorm && gc, NGAN_ERR_ARG, "lrelu_pixelnorm_bwd: null pointer");
-    if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C)) return ngan::wide_pn_bwd(gy, gy2, gr, y, rnorm, gc, npix, C, slope, (hipStream_t)stream);
+    if constexpr (sizeof(T) == 4)
+        if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C)) return ngan::wide_pn_bwd(gy, gy2, gr, y, rnorm, gc, npix, C, slope, (hipStream_t)stream);
     NGAN_REQUIRE(npix > 0 && lpp_ok(C), NGAN_ERR_SHAPE, "lrelu_pixelnorm_bwd: npix=%ld C=%d unsupported", npix, C);
     PN_DISPATCH(pn_bwd_kernel, gy, gr, y, rnorm, gc, npix, C, slope, gy2);
     return ngan::launch_status("ngan_lrelu_pixelnorm_bwd");
+}
+
+template <typename T>
+int pn_bwdbwd_impl(const T* h, const T* gy, const T* y, const float* rnorm, T* ggy, T* gy_out, float* gr_out, long npix, int C, float slope,
+                   void* stream) {
+    NGAN_REQUIRE(h && gy && y && rnorm && ggy && gy_out && gr_out, NGAN_ERR_ARG, "lrelu_pixelnorm_bwdbwd: null pointer");
+    if constexpr (sizeof(T) == 4)
+        if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C))
+            return ngan::wide_pn_bwdbwd(h, gy, y, rnorm, ggy, gy_out, gr_out, npix, C, slope, (hipStream_t)stream);
+    NGAN_REQUIRE(npix > 0 && lpp_ok(C), NGAN_ERR_SHAPE, "lrelu_pixelnorm_bwdbwd: npix=%ld C=%d unsupported", npix, C);
+    PN_DISPATCH(pn_bwdbwd_kernel, h, gy, y, rnorm, ggy, gy_out, gr_out, npix, C, slope);
+    return ngan::launch_status("ngan_lrelu_pixelnorm_bwdbwd");
+}
+
+}  // namespace
+
+#define BF(p) reinterpret_cast<const __bf16*>(p)
+#define BFM(p) reinterpret_cast<__bf16*>(p)
+
+extern "C" int ngan_lrelu_pixelnorm_fwd(const float* c, const float* bias, float* y, float* rnorm, long npix, int C,
+                                        float slope, float eps, void* stream) {
+    return pn_fwd_impl<float>(c, bias, y, rnorm, npix, C, slope, eps, stream);
+}
+extern "C" int ngan_bf16_lrelu_pixelnorm_fwd(const ngan_bf16* c, const float* bias, ngan_bf16* y, float* rnorm, long npix, int C,
+                                             float slope, float eps, void* stream) {
+    return pn_fwd_impl<__bf16>(BF(c), bias, BFM(y), rnorm, npix, C, slope, eps, stream);
+}
+
+extern "C" int ngan_lrelu_pixelnorm_bwd2(const float* gy, const float* gy2, const float* gr, const float* y, const float* rnorm,
+                                         float* gc, long npix, int C, float slope, void* stream) {
+    return pn_bwd2_impl<float>(gy, gy2, gr, y, rnorm, gc, npix, C, slope, stream);
+}
+extern "C" int ngan_bf16_lrelu_pixelnorm_bwd2(const ngan_bf16* gy, const ngan_bf16* gy2, const float* gr, const ngan_bf16* y, const float* rnorm,
+                                              ngan_bf16* gc, long npix, int C, float slope, void* stream) {
+    return pn_bwd2_impl<__bf16>(BF(gy), BF(gy2), gr, BF(y), rnorm, BFM(gc), npix, C, slope, stream);
 }
 
 extern "C" int ngan_lrelu_pixelnorm_bwd(const float* gy, const float* gr, const float* y, const float* rnorm, float* gc,
                                         long npix, int C, float slope, void* stream) {
     return ngan_lrelu_pixelnorm_bwd2(gy, nullptr, gr, y, rnorm, gc, npix, C, slope, stream);
 }
+extern "C" int ngan_bf16_lrelu_pixelnorm_bwd(const ngan_bf16* gy, const float* gr, const ngan_bf16* y, const float* rnorm, ngan_bf16* gc,
+                                             long npix, int C, float slope, void* stream) {
+    return ngan_bf16_lrelu_pixelnorm_bwd2(gy, nullptr, gr, y, rnorm, gc, npix, C, slope, stream);
+}
 
 extern "C" int ngan_lrelu_pixelnorm_bwdbwd(const float* h, const float* gy, const float* y, const float* rnorm,
                                            float* ggy, float* gy_out, float* gr_out, long npix, int C, float slope,
                                            void* stream) {
-    NGAN_REQUIRE(h && gy && y && rnorm && ggy && gy_out && gr_out, NGAN_ERR_ARG, "lrelu_pixelnorm_bwdbwd: null pointer");
-    if (npix > 0 && C > 0 && C % 4 == 0 && !lpp_ok(C)) return ngan::wide_pn_bwdbwd(h, gy, y, rnorm, ggy, gy_out, gr_out, npix, C, slope, (hipStream_t)stream);
-    NGAN_REQUIRE(npix > 0 && lpp_ok(C), NGAN_ERR_SHAPE, "lrelu_pixelnorm_bwdbwd: npix=%ld C=%d unsupported", npix, C);
-    PN_DISPATCH(pn_bwdbwd_kernel, h, gy, y, rnorm, ggy, gy_out, gr_out, npix, C, slope);
-    return ngan::launch_status("ngan_lrelu_pixelnorm_bwdbwd");
+    return pn_bwdbwd_impl<float>(h, gy, y, rnorm, ggy, gy_out, gr_out, npix, C, slope, stream);
+}
+extern "C" int ngan_bf16_lrelu_pixelnorm_bwdbwd(const ngan_bf16* h, const ngan_bf16* gy, const ngan_bf16* y, const float* rnorm,
+                                                ngan_bf16* ggy, ngan_bf16* gy_out, float* gr_out, long npix, int C, float slope, void* stream) {
+    return pn_bwdbwd_impl<__bf16>(BF(h), BF(gy), BF(y), rnorm, BFM(ggy), BFM(gy_out), gr_out, npix, C, slope, stream);
 }

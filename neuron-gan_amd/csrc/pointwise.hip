@@ -90,14 +90,14 @@ __device__ __forceinline__ float4 block_quad_sum(float4 v, float4* red) {
 // ------------------------------------------------------------------------------------------------------------
 // channel sums (bias gradient)
 // ------------------------------------------------------------------------------------------------------------
-template <int Q>
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ partial,
+template <typename T, int Q>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ g, float* __restrict__ partial,
                                                           long npix, int C) {
     __shared__ float4 red[256];
     const int tid = threadIdx.x, sub = tid % Q;
     const long stride = (long)gridDim.x * (256 / Q);
     float4 acc = f4zero();
-    for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) acc = f4add(acc, ld4(g + pix * C + sub * 4));
+    for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) acc = f4add(acc, lda4(g + pix * C + sub * 4));
     float4 s = block_quad_sum<Q>(acc, red);
     if (tid < Q) st4(partial + (long)blockIdx.x * C + tid * 4, s);
 }
@@ -114,9 +114,9 @@ __device__ __forceinline__ float load_img(const float* __restrict__ x, int b, in
 }
 
 // one thread per (pixel, channel quad); blockIdx.y = image row (b*H + y), so no per-item division by W or H
-template <int POOL>
+template <typename T, int POOL>
 __global__ __launch_bounds__(256) void from_image_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             const float* __restrict__ bias, T* __restrict__ y,
                                                              int B, int H, int W, int Ncol, int C) {
     const unsigned Q = C / 4;
     const unsigned it = blockIdx.x * 256 + threadIdx.x;        // item inside the row: xx * Q + channel quad
@@ -131,18 +131,18 @@ __global__ __launch_bounds__(256) void from_image_fwd_kernel(const float* __rest
         o.x = fmaf(w[(c0 + 0) * Ncol + k], v, o.x); o.y = fmaf(w[(c0 + 1) * Ncol + k], v, o.y);
         o.z = fmaf(w[(c0 + 2) * Ncol + k], v, o.z); o.w = fmaf(w[(c0 + 3) * Ncol + k], v, o.w);
     }
-    st4(y + ((long)row * W + xx) * C + c0, o);
+    sta4(y + ((long)row * W + xx) * C + c0, o);
 }
 
-template <int Q, int POOL>
-__global__ __launch_bounds__(256) void from_image_dx_kernel(const float* __restrict__ g, const float* __restrict__ w,
+template <typename T, int Q, int POOL>
+__global__ __launch_bounds__(256) void from_image_dx_kernel(const T* __restrict__ g, const float* __restrict__ w,
                                                             float* __restrict__ gx, int B, int H, int W, int Ncol, int C) {
     const unsigned npix = (unsigned)B * H * W;            // host checks that npix * Q fits 31 bits
     const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned pix = gid / Q;
     const int sub = (int)(gid % Q);
     const bool ok = pix < npix;
-    const float4 gv = ok ? ld4(g + (long)pix * C + sub * 4) : f4zero();
+    const float4 gv = ok ? lda4(g + (long)pix * C + sub * 4) : f4zero();
     const unsigned row = pix / (unsigned)W;
     const int xx = (int)(pix - row * W);
     const int b = (int)(row / (unsigned)H);
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void from_image_dx_kernel(const float* __restr
 }
 
 // partial slab per block: [c*Ncol + k] for k < Ncol, then [C*Ncol + c] for the bias sums
-template <int Q, int POOL>
-__global__ __launch_bounds__(256) void from_image_dw_kernel(const float* __restrict__ x, const float* __restrict__ g,
+template <typename T, int Q, int POOL>
+__global__ __launch_bounds__(256) void from_image_dw_kernel(const float* __restrict__ x, const T* __restrict__ g,
                                                             float* __restrict__ partial, int B, int H, int W, int Ncol, int C,
                                                             int rows_per_block) {
     __shared__ float4 red[256];
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void from_image_dw_kernel(const float* __restr
     for (int k = 0; k < 5; ++k) acc[k] = f4zero();
     for (int row = r0; row < r1; ++row) {
         const int b = row / H, yy = row - b * H;
-        const float* grow = g + (long)row * W * C + sub * 4;
+        const T* grow = g + (long)row * W * C + sub * 4;
         for (int x0 = tid / Q; x0 < W; x0 += 4 * PPB) {
             float4 gv[4];
             float xv[4][4];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void from_image_dw_kernel(const float* __restr
             for (int u = 0; u < 4; ++u) {
                 const int xu = x0 + u * PPB;
                 const int xx = xu < W ? xu : W - 1;
-                gv[u] = ld4(grow + (long)xx * C);
+                gv[u] = lda4(grow + (long)xx * C);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xv[u][k] = k < Ncol ? load_img<POOL>(x, b, yy, xx, k, H, W, Ncol) : 0.f;
             }
@@ -221,14 +221,14 @@ __global__ __launch_bounds__(256) void from_image_dw_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------------------
 // ToImage
 // ------------------------------------------------------------------------------------------------------------
-template <int Q>
-__global__ __launch_bounds__(256) void to_image_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T, int Q>
+__global__ __launch_bounds__(256) void to_image_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                            float* __restrict__ t, long npix, int C, int Ncol) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long pix = gid / Q;
     const int sub = (int)(gid % Q);
     const bool ok = pix < npix;
-    const float4 xv = ok ? ld4(x + pix * C + sub * 4) : f4zero();
+    const float4 xv = ok ? lda4(x + pix * C + sub * 4) : f4zero();
     for (int k = 0; k < Ncol; ++k) {
         const float s = group_sum<Q>(f4dot(xv, ld4(w + k * C + sub * 4)));
         if (ok && sub == 0) t[pix * Ncol + k] = tanhf(s);
@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256) void to_image_fwd_kernel(const float* __restri
 
 // rn != nullptr: x is the output of a LeakyReLU -> PixelNorm with norms rn, and gx receives the gradient w.r.t. that operator's
 // INPUT (its backward is applied to the ToImage input-gradient before the store: one pass instead of two over the activation)
-template <int Q>
+template <typename T, int Q>
 __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restrict__ g, const float* __restrict__ t,
-                                                           const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ gx, float* __restrict__ partial,
+                                                           const T* __restrict__ x, const float* __restrict__ w,
+                                                           T* __restrict__ gx, float* __restrict__ partial,
                                                            long npix, int C, int Ncol, const float* __restrict__ rn, float slope) {
     __shared__ float4 red[256];
     const int tid = threadIdx.x, sub = tid % Q;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restri
     // (the trip count is the same for all Q lanes of a pixel group only if npix is a multiple of 256 / Q per stride step; lanes of
     // one pixel always iterate together, which is all the group shuffle below needs)
     for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) {
-        const float4 xv = ld4(x + pix * C + sub * 4);
+        const float4 xv = lda4(x + pix * C + sub * 4);
         float4 o = f4zero();
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restri
             const float sdot = group_sum<Q>(f4dot(o, xv)) * (1.0f / (float)C);
             o = pn_bwd4_pw(o, xv, sdot, 1.0f / rn[pix], slope);
         }
-        st4(gx + pix * C + sub * 4, o);
+        sta4(gx + pix * C + sub * 4, o);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------------------
 // resampling (scalar per element; used on colour images and on feature maps outside fused convs)
 // ------------------------------------------------------------------------------------------------------------
-__global__ void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C) {
+template <typename T>
+__global__ void up2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int h, int w, int C) {
     const long total = (long)B * 4 * h * w * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -292,11 +293,11 @@ __global__ void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
         int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
         up2_taps(Y, h, y0, y1, wy0, wy1);
         up2_taps(X, w, x0, x1, wx0, wx1);
-        const float* r0 = x + ((long)b * h + y0) * w * C + c;
-        const float* r1 = x + ((long)b * h + y1) * w * C + c;
-        const float top = fmaf(r0[(long)x1 * C], wx1, r0[(long)x0 * C] * wx0);
-        const float bot = fmaf(r1[(long)x1 * C], wx1, r1[(long)x0 * C] * wx0);
-        y[i] = fmaf(bot, wy1, top * wy0);
+        const T* r0 = x + ((long)b * h + y0) * w * C + c;
+        const T* r1 = x + ((long)b * h + y1) * w * C + c;
+        const float top = fmaf(lda1(r0 + (long)x1 * C), wx1, lda1(r0 + (long)x0 * C) * wx0);
+        const float bot = fmaf(lda1(r1 + (long)x1 * C), wx1, lda1(r1 + (long)x0 * C) * wx0);
+        sta1(y + i, fmaf(bot, wy1, top * wy0));
     }
 }
 
@@ -309,7 +310,8 @@ __device__ __forceinline__ float up2_adj_w(int i, int R, int n) {
     return i == n - 1 ? 1.0f : 0.75f;  // d == 1
 }
 
-__global__ void up2_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int h, int w, int C) {
+template <typename T>
+__global__ void up2_adjoint_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int h, int w, int C) {
     const long total = (long)B * h * w * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -326,15 +328,16 @@ __global__ void up2_adjoint_kernel(const float* __restrict__ gy, float* __restri
                 const int RX = 2 * X + dx;
                 const float wx = up2_adj_w(X, RX, w);
                 if (wx == 0.f) continue;
-                s = fmaf(wy * wx, gy[(((long)b * 2 * h + RY) * (2 * w) + RX) * C + c], s);
+                s = fmaf(wy * wx, lda1(gy + (((long)b * 2 * h + RY) * (2 * w) + RX) * C + c), s);
             }
         }
-        gx[i] = s;
+        sta1(gx + i, s);
     }
 }
 
 // float4 version (C % 4 == 0): one thread per (low-res pixel, channel quad)
-__global__ __launch_bounds__(256) void up2_adjoint_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int h,
+template <typename T>
+__global__ __launch_bounds__(256) void up2_adjoint_vec_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int h,
                                                               int w, int C) {
     const int Q = C >> 2;
     const long total = (long)B * h * w * Q;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void up2_adjoint_vec_kernel(const float* __res
         const int X = (int)(r % w); r /= w;
         const int Y = (int)(r % h);
         const int b = (int)(r / h);
-        const float* base = gy + (long)b * 4 * h * w * C + c4 * 4;
+        const T* base = gy + (long)b * 4 * h * w * C + c4 * 4;
         float4 s = f4zero();
 #pragma unroll
         for (int dy = -1; dy <= 2; ++dy) {
@@ -356,11 +359,11 @@ __global__ __launch_bounds__(256) void up2_adjoint_vec_kernel(const float* __res
             for (int dx = -1; dx <= 2; ++dx) {
                 const int RX = 2 * X + dx;
                 const float wx = up2_adj_w(X, RX, w);
-                if (wx != 0.f) rowsum = f4fma(ld4(base + ((long)RY * (2 * w) + RX) * C), wx, rowsum);
+                if (wx != 0.f) rowsum = f4fma(lda4(base + ((long)RY * (2 * w) + RX) * C), wx, rowsum);
             }
             s = f4fma(rowsum, wy, s);
         }
-        st4(gx + i * 4, s);
+        sta4(gx + i * 4, s);
     }
 }
 
@@ -369,9 +372,9 @@ __global__ __launch_bounds__(256) void up2_adjoint_vec_kernel(const float* __res
 // reuses the two it combined for the previous output -- 8 sixteen-byte loads per output instead of 16, no divergent control
 // flow, so all of them are in flight together.  PNBWD: the result is the gradient w.r.t. the output y of a LeakyReLU -> PixelNorm;
 // apply that operator's backward in the same pass (gc = m * (g - y*mean_c(g*y)) / r), saving a full read + write of the tensor.
-template <int Q, int PNBWD>
-__global__ __launch_bounds__(256) void up2_adjoint_strip_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                                const float* __restrict__ yprev, const float* __restrict__ rn,
+template <typename T, int Q, int PNBWD>
+__global__ __launch_bounds__(256) void up2_adjoint_strip_kernel(const T* __restrict__ gy, T* __restrict__ gx,
+                                                                const T* __restrict__ yprev, const float* __restrict__ rn,
                                                                 int h, int w, float slope, int YT) {
     constexpr int C = 4 * Q;
     const int tid = threadIdx.x, c4 = tid % Q;
@@ -388,13 +391,13 @@ __global__ __launch_bounds__(256) void up2_adjoint_strip_kernel(const float* __r
         wx[k] = up2_adj_w(Xc, RX, w);
         rx[k] = min(max(RX, 0), W2 - 1) * C + c4 * 4;
     }
-    const float* base = gy + (long)b * H2 * W2 * C;
+    const T* base = gy + (long)b * H2 * W2 * C;
     auto hrow = [&](int RY) {
-        const float* r = base + (long)min(max(RY, 0), H2 - 1) * W2 * C;
-        float4 a = f4scale(ld4(r + rx[0]), wx[0]);
-        a = f4fma(ld4(r + rx[1]), wx[1], a);
-        a = f4fma(ld4(r + rx[2]), wx[2], a);
-        return f4fma(ld4(r + rx[3]), wx[3], a);
+        const T* r = base + (long)min(max(RY, 0), H2 - 1) * W2 * C;
+        float4 a = f4scale(lda4(r + rx[0]), wx[0]);
+        a = f4fma(lda4(r + rx[1]), wx[1], a);
+        a = f4fma(lda4(r + rx[2]), wx[2], a);
+        return f4fma(lda4(r + rx[3]), wx[3], a);
     };
     const int Ys = blockIdx.y * YT, Ye = min(Ys + YT, h);
     float4 r_m1 = hrow(2 * Ys - 1), r_0 = hrow(2 * Ys);
@@ -406,16 +409,17 @@ __global__ __launch_bounds__(256) void up2_adjoint_strip_kernel(const float* __r
         sacc = f4fma(r_2, up2_adj_w(Y, 2 * Y + 2, h), sacc);
         const long pix = ((long)b * h + Y) * w + Xc;
         if (PNBWD) {
-            const float4 yy = ld4(yprev + pix * C + c4 * 4);
+            const float4 yy = lda4(yprev + pix * C + c4 * 4);
             const float dot = group_sum<Q>(f4dot(sacc, yy)) * (1.0f / (float)C);
             sacc = pn_bwd4_pw(sacc, yy, dot, 1.0f / rn[pix], slope);
         }
-        if (xok) st4(gx + pix * C + c4 * 4, sacc);
+        if (xok) sta4(gx + pix * C + c4 * 4, sacc);
         r_m1 = r_1; r_0 = r_2;
     }
 }
 
-__global__ void pool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int h, int w, int C) {
+template <typename T>
+__global__ void pool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int h, int w, int C) {
     const long total = (long)B * h * w * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -424,14 +428,15 @@ __global__ void pool2_fwd_kernel(const float* __restrict__ x, float* __restrict_
         const int Y = (int)(r % h);
         const int b = (int)(r / h);
         const long W2 = 2L * w;
-        const float* p = x + (((long)b * 2 * h + 2 * Y) * W2 + 2 * X) * C + c;
-        y[i] = 0.25f * ((p[0] + p[C]) + (p[W2 * C] + p[W2 * C + C]));
+        const T* p = x + (((long)b * 2 * h + 2 * Y) * W2 + 2 * X) * C + c;
+        sta1(y + i, 0.25f * ((lda1(p) + lda1(p + C)) + (lda1(p + W2 * C) + lda1(p + W2 * C + C))));
     }
 }
 
 // the same for C a multiple of 4: a thread takes 4 channels of an output pixel (4 x 16-byte loads, one 16-byte store); 32-bit
 // index arithmetic (the host checks the element count).  Same association as the scalar kernel: bit-identical.
-__global__ __launch_bounds__(256) void pool2_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y, int total4, int h, int w, int C4) {
+template <typename T>
+__global__ __launch_bounds__(256) void pool2_fwd_v4_kernel(const T* __restrict__ x, T* __restrict__ y, int total4, int h, int w, int C4) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     const int c4 = i % C4;
@@ -439,13 +444,14 @@ __global__ __launch_bounds__(256) void pool2_fwd_v4_kernel(const float* __restri
     const int X = r % w; r /= w;                    // r = b * h + Y from here on
     const int C = 4 * C4;
     const long row = (long)2 * w * C;
-    const float* p = x + ((long)2 * r * 2 * w + 2 * X) * C + 4 * c4;
-    const float4 a = ld4(p), b = ld4(p + C), c = ld4(p + row), d = ld4(p + row + C);
-    st4(y + (long)i * 4, make_float4(0.25f * ((a.x + b.x) + (c.x + d.x)), 0.25f * ((a.y + b.y) + (c.y + d.y)),
+    const T* p = x + ((long)2 * r * 2 * w + 2 * X) * C + 4 * c4;
+    const float4 a = lda4(p), b = lda4(p + C), c = lda4(p + row), d = lda4(p + row + C);
+    sta4(y + (long)i * 4, make_float4(0.25f * ((a.x + b.x) + (c.x + d.x)), 0.25f * ((a.y + b.y) + (c.y + d.y)),
                                      0.25f * ((a.z + b.z) + (c.z + d.z)), 0.25f * ((a.w + b.w) + (c.w + d.w))));
 }
 
-__global__ void pool2_adjoint_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int h, int w, int C) {
+template <typename T>
+__global__ void pool2_adjoint_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int h, int w, int C) {
     const long total = (long)B * 4 * h * w * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -453,18 +459,21 @@ __global__ void pool2_adjoint_kernel(const float* __restrict__ gy, float* __rest
         const int X = (int)(r % (2 * w)); r /= (2 * w);
         const int Y = (int)(r % (2 * h));
         const int b = (int)(r / (2 * h));
-        gx[i] = 0.25f * gy[(((long)b * h + (Y >> 1)) * w + (X >> 1)) * C + c];
+        sta1(gx + i, 0.25f * lda1(gy + (((long)b * h + (Y >> 1)) * w + (X >> 1)) * C + c));
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // elementwise arithmetic
 // ------------------------------------------------------------------------------------------------------------
-__global__ void lerp_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ alpha,
-                            float* __restrict__ out, long n) {
+template <typename T>
+__global__ void lerp_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ alpha,
+                            T* __restrict__ out, long n) {
     const float al = alpha[0];
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = fmaf(al, b[i] - a[i], a[i]);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float av = lda1(a + i);
+        sta1(out + i, fmaf(al, lda1(b + i) - av, av));
+    }
 }
 
 __global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float ca, float cb,
@@ -473,13 +482,14 @@ __global__ void axpby_kernel(const float* __restrict__ a, const float* __restric
         out[i] = b ? fmaf(cb, b[i], ca * a[i]) : ca * a[i];
 }
 
-__global__ void fade_bwd_kernel(const float* __restrict__ g, const float* __restrict__ alpha, float* __restrict__ ga,
-                                float* __restrict__ gb, long n) {
+template <typename T>
+__global__ void fade_bwd_kernel(const T* __restrict__ g, const float* __restrict__ alpha, T* __restrict__ ga,
+                                T* __restrict__ gb, long n) {
     const float al = alpha[0];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float v = g[i];
-        ga[i] = (1.0f - al) * v;
-        gb[i] = al * v;
+        const float v = lda1(g + i);
+        sta1(ga + i, (1.0f - al) * v);
+        sta1(gb + i, al * v);
     }
 }
 
@@ -650,29 +660,45 @@ extern "C" int ngan_gp_coef(const float* norms, int B, float lambda, const float
 }
 
 
-extern "C" int ngan_channel_sum_acc(const float* g, float* out, float* workspace, long npix, int C, float scale, int accumulate, void* stream) {
+// ---- entry points over the activation type: T = float is the fp32 contract of include/ngan.h (csrc/wide.hip behind it for channel counts
+// outside the lane-group kernels' range), T = __bf16 the "bf16 activation storage" section (no wide path: NGAN_ERR_SHAPE instead)
+#define BF(p) reinterpret_cast<const __bf16*>(p)
+#define BFM(p) reinterpret_cast<__bf16*>(p)
+template <typename T> constexpr bool is_f32() { return sizeof(T) == 4; }
+
+template <typename T>
+static int channel_sum_impl(const T* g, float* out, float* workspace, long npix, int C, float scale, int accumulate, void* stream) {
     NGAN_REQUIRE(g && out && workspace, NGAN_ERR_ARG, "channel_sum: null pointer");
-    if (npix > 0 && C > 0 && !pow2_quads(C)) {                                                                                    // wide.hip
-        NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "channel_sum: accumulate is not available for C=%d", C);
-        return ngan::wide_channel_sum(g, out, npix, C, scale, (hipStream_t)stream);
-    }
+    if constexpr (is_f32<T>())
+        if (npix > 0 && C > 0 && !pow2_quads(C)) {                                                                                // wide.hip
+            NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "channel_sum: accumulate is not available for C=%d", C);
+            return ngan::wide_channel_sum(g, out, npix, C, scale, (hipStream_t)stream);
+        }
     NGAN_REQUIRE(npix > 0 && pow2_quads(C), NGAN_ERR_SHAPE, "channel_sum: npix=%ld C=%d unsupported", npix, C);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = stream_blocks(npix, C / 4);
-#define CALL(QV) hipLaunchKernelGGL((channel_sum_kernel<QV>), dim3(nblk), dim3(256), 0, s, g, workspace, npix, C)
+#define CALL(QV) hipLaunchKernelGGL((channel_sum_kernel<T, QV>), dim3(nblk), dim3(256), 0, s, g, workspace, npix, C)
     Q_DISPATCH(CALL)
 #undef CALL
     int st = ngan::launch_status("ngan_channel_sum");
     if (st) return st;
     return ngan::reduce_partials_acc(workspace, nblk, C, C, out, C, nullptr, scale, accumulate ? 1 : 0, s);
 }
-
+extern "C" int ngan_channel_sum_acc(const float* g, float* out, float* workspace, long npix, int C, float scale, int accumulate, void* stream) {
+    return channel_sum_impl<float>(g, out, workspace, npix, C, scale, accumulate, stream);
+}
 extern "C" int ngan_channel_sum(const float* g, float* out, float* workspace, long npix, int C, float scale, void* stream) {
-    return ngan_channel_sum_acc(g, out, workspace, npix, C, scale, 0, stream);
+    return channel_sum_impl<float>(g, out, workspace, npix, C, scale, 0, stream);
+}
+extern "C" int ngan_bf16_channel_sum_acc(const ngan_bf16* g, float* out, float* workspace, long npix, int C, float scale, int accumulate, void* stream) {
+    return channel_sum_impl<__bf16>(BF(g), out, workspace, npix, C, scale, accumulate, stream);
+}
+extern "C" int ngan_bf16_channel_sum(const ngan_bf16* g, float* out, float* workspace, long npix, int C, float scale, void* stream) {
+    return channel_sum_impl<__bf16>(BF(g), out, workspace, npix, C, scale, 0, stream);
 }
 
-extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int Ncol,
-                                   int C, int pool, void* stream) {
+template <typename T>
+static int from_image_fwd_impl(const float* x, const float* w, const float* b, T* y, int B, int H, int W, int Ncol, int C, int pool, void* stream) {
     NGAN_REQUIRE(x && w && y, NGAN_ERR_ARG, "from_image_fwd: null pointer");
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0, NGAN_ERR_SHAPE,
                  "from_image_fwd: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
@@ -680,45 +706,56 @@ extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* 
     hipStream_t s = (hipStream_t)stream;
     NGAN_REQUIRE((long)B * H < 65536, NGAN_ERR_SHAPE, "from_image_fwd: B*H must be below 65536");
     const dim3 grid(ceil_div((long)W * (C / 4), 256), B * H);
-    if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<1>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
-    else hipLaunchKernelGGL((from_image_fwd_kernel<0>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<T, 1>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    else hipLaunchKernelGGL((from_image_fwd_kernel<T, 0>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
     return ngan::launch_status("ngan_from_image_fwd");
 }
+extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int Ncol,
+                                   int C, int pool, void* stream) {
+    return from_image_fwd_impl<float>(x, w, b, y, B, H, W, Ncol, C, pool, stream);
+}
+extern "C" int ngan_bf16_from_image_fwd(const float* x, const float* w, const float* b, ngan_bf16* y, int B, int H, int W, int Ncol,
+                                        int C, int pool, void* stream) {
+    return from_image_fwd_impl<__bf16>(x, w, b, BFM(y), B, H, W, Ncol, C, pool, stream);
+}
 
-extern "C" int ngan_from_image_dx(const float* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool,
-                                  void* stream) {
+template <typename T>
+static int from_image_dx_impl(const T* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool, void* stream) {
     NGAN_REQUIRE(g && w && gx, NGAN_ERR_ARG, "from_image_dx: null pointer");
-    if (B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && !pow2_quads(C))
-        return ngan::wide_from_image_dx(g, w, gx, B, H, W, Ncol, C, pool, (hipStream_t)stream);                                 // wide.hip
+    if constexpr (is_f32<T>())
+        if (B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && !pow2_quads(C))
+            return ngan::wide_from_image_dx(g, w, gx, B, H, W, Ncol, C, pool, (hipStream_t)stream);                             // wide.hip
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
                  "from_image_dx: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
     NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_dx: B*H*W*C/4 must be below 2^31");
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div((long)B * H * W * (C / 4), 256);
 #define CALL(QV)                                                                                                     \
-    if (pool) hipLaunchKernelGGL((from_image_dx_kernel<QV, 1>), dim3(nblk), dim3(256), 0, s, g, w, gx, B, H, W, Ncol, C); \
-    else hipLaunchKernelGGL((from_image_dx_kernel<QV, 0>), dim3(nblk), dim3(256), 0, s, g, w, gx, B, H, W, Ncol, C)
+    if (pool) hipLaunchKernelGGL((from_image_dx_kernel<T, QV, 1>), dim3(nblk), dim3(256), 0, s, g, w, gx, B, H, W, Ncol, C); \
+    else hipLaunchKernelGGL((from_image_dx_kernel<T, QV, 0>), dim3(nblk), dim3(256), 0, s, g, w, gx, B, H, W, Ncol, C)
     Q_DISPATCH(CALL)
 #undef CALL
     return ngan::launch_status("ngan_from_image_dx");
 }
-
-extern "C" int ngan_from_image_dw_acc(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
-                                      int Ncol, int C, int pool, int accumulate, void* stream);
-
-extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
-                                  int Ncol, int C, int pool, void* stream) {
-    return ngan_from_image_dw_acc(x, g, gw, gb, workspace, B, H, W, Ncol, C, pool, 0, stream);
+extern "C" int ngan_from_image_dx(const float* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool,
+                                  void* stream) {
+    return from_image_dx_impl<float>(g, w, gx, B, H, W, Ncol, C, pool, stream);
+}
+extern "C" int ngan_bf16_from_image_dx(const ngan_bf16* g, const float* w, float* gx, int B, int H, int W, int Ncol, int C, int pool,
+                                       void* stream) {
+    return from_image_dx_impl<__bf16>(BF(g), w, gx, B, H, W, Ncol, C, pool, stream);
 }
 
 // accumulate: bit 0 gw += , bit 1 gb +=
-extern "C" int ngan_from_image_dw_acc(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
-                                      int Ncol, int C, int pool, int accumulate, void* stream) {
+template <typename T>
+static int from_image_dw_impl(const float* x, const T* g, float* gw, float* gb, float* workspace, int B, int H, int W,
+                              int Ncol, int C, int pool, int accumulate, void* stream) {
     NGAN_REQUIRE(x && g && gw && workspace, NGAN_ERR_ARG, "from_image_dw: null pointer");
-    if (B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && !pow2_quads(C)) {
-        NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "from_image_dw: accumulate is not available for C=%d", C);
-        return ngan::wide_from_image_dw(x, g, gw, gb, B, H, W, Ncol, C, pool, (hipStream_t)stream);                             // wide.hip
-    }
+    if constexpr (is_f32<T>())
+        if (B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && !pow2_quads(C)) {
+            NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "from_image_dw: accumulate is not available for C=%d", C);
+            return ngan::wide_from_image_dw(x, g, gw, gb, B, H, W, Ncol, C, pool, (hipStream_t)stream);                         // wide.hip
+        }
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE,
                  "from_image_dw: B=%d H=%d W=%d Ncol=%d C=%d unsupported", B, H, W, Ncol, C);
     NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_dw: B*H*W*C/4 must be below 2^31");
@@ -727,9 +764,9 @@ extern "C" int ngan_from_image_dw_acc(const float* x, const float* g, float* gw,
     const int rpb_min = ceil_div(rows, MAX_PARTS), rpb_pref = rows >= 2048 ? 4 : 1;
     const int rpb = rpb_min > rpb_pref ? rpb_min : rpb_pref;
     const int nblk = ceil_div(rows, rpb);                 // <= MAX_PARTS slabs (the callers' workspace holds 1024)
-#define CALL(QV)                                                                                                                   \
-    if (pool) hipLaunchKernelGGL((from_image_dw_kernel<QV, 1>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C, rpb); \
-    else hipLaunchKernelGGL((from_image_dw_kernel<QV, 0>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C, rpb)
+#define CALL(QV)                                                                                                                      \
+    if (pool) hipLaunchKernelGGL((from_image_dw_kernel<T, QV, 1>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C, rpb); \
+    else hipLaunchKernelGGL((from_image_dw_kernel<T, QV, 0>), dim3(nblk), dim3(256), 0, s, x, g, workspace, B, H, W, Ncol, C, rpb)
     Q_DISPATCH(CALL)
 #undef CALL
     int st = ngan::launch_status("ngan_from_image_dw");
@@ -738,79 +775,138 @@ extern "C" int ngan_from_image_dw_acc(const float* x, const float* g, float* gw,
     if (!gb) return ngan::reduce_partials_acc(workspace, nblk, C * Ncol, stride, gw, C * Ncol, nullptr, 1.0f, accumulate & 1, s);
     return ngan::reduce_partials_acc(workspace, nblk, C * (Ncol + 1), stride, gw, C * Ncol, gb, 1.0f, accumulate, s);   // weight and bias sums: one launch
 }
+extern "C" int ngan_from_image_dw_acc(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
+                                      int Ncol, int C, int pool, int accumulate, void* stream) {
+    return from_image_dw_impl<float>(x, g, gw, gb, workspace, B, H, W, Ncol, C, pool, accumulate, stream);
+}
+extern "C" int ngan_from_image_dw(const float* x, const float* g, float* gw, float* gb, float* workspace, int B, int H, int W,
+                                  int Ncol, int C, int pool, void* stream) {
+    return from_image_dw_impl<float>(x, g, gw, gb, workspace, B, H, W, Ncol, C, pool, 0, stream);
+}
+extern "C" int ngan_bf16_from_image_dw_acc(const float* x, const ngan_bf16* g, float* gw, float* gb, float* workspace, int B, int H, int W,
+                                           int Ncol, int C, int pool, int accumulate, void* stream) {
+    return from_image_dw_impl<__bf16>(x, BF(g), gw, gb, workspace, B, H, W, Ncol, C, pool, accumulate, stream);
+}
+extern "C" int ngan_bf16_from_image_dw(const float* x, const ngan_bf16* g, float* gw, float* gb, float* workspace, int B, int H, int W,
+                                       int Ncol, int C, int pool, void* stream) {
+    return from_image_dw_impl<__bf16>(x, BF(g), gw, gb, workspace, B, H, W, Ncol, C, pool, 0, stream);
+}
 
-extern "C" int ngan_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, void* stream) {
+template <typename T>
+static int to_image_fwd_impl(const T* x, const float* w, float* t, long npix, int C, int Ncol, void* stream) {
     NGAN_REQUIRE(x && w && t, NGAN_ERR_ARG, "to_image_fwd: null pointer");
-    if (npix > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0 && !pow2_quads(C))
-        return ngan::wide_to_image_fwd(x, w, t, npix, C, Ncol, (hipStream_t)stream);                                            // wide.hip
+    if constexpr (is_f32<T>())
+        if (npix > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0 && !pow2_quads(C))
+            return ngan::wide_to_image_fwd(x, w, t, npix, C, Ncol, (hipStream_t)stream);                                        // wide.hip
     NGAN_REQUIRE(npix > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE, "to_image_fwd: npix=%ld C=%d Ncol=%d unsupported",
                  npix, C, Ncol);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = ceil_div(npix * (C / 4), 256);
-#define CALL(QV) hipLaunchKernelGGL((to_image_fwd_kernel<QV>), dim3(nblk), dim3(256), 0, s, x, w, t, npix, C, Ncol)
+#define CALL(QV) hipLaunchKernelGGL((to_image_fwd_kernel<T, QV>), dim3(nblk), dim3(256), 0, s, x, w, t, npix, C, Ncol)
     Q_DISPATCH(CALL)
 #undef CALL
     return ngan::launch_status("ngan_to_image_fwd");
 }
-
-static int to_image_bwd_impl(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
-                             float* workspace, long npix, int C, int Ncol, const float* rn, float slope, int accumulate, void* stream);
-
-extern "C" int ngan_to_image_bwd(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
-                                 float* workspace, long npix, int C, int Ncol, void* stream) {
-    return to_image_bwd_impl(g, t, x, w, gx, gw, workspace, npix, C, Ncol, nullptr, 0.f, 0, stream);
+extern "C" int ngan_to_image_fwd(const float* x, const float* w, float* t, long npix, int C, int Ncol, void* stream) {
+    return to_image_fwd_impl<float>(x, w, t, npix, C, Ncol, stream);
+}
+extern "C" int ngan_bf16_to_image_fwd(const ngan_bf16* x, const float* w, float* t, long npix, int C, int Ncol, void* stream) {
+    return to_image_fwd_impl<__bf16>(BF(x), w, t, npix, C, Ncol, stream);
 }
 
-extern "C" int ngan_to_image_bwd_pnbwd(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
-                                       float* gw, float* workspace, long npix, int C, int Ncol, float slope, void* stream) {
-    NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
-    return to_image_bwd_impl(g, t, y, w, gc, gw, workspace, npix, C, Ncol, rnorm, slope, 0, stream);
-}
-
-// the same with gw += (accumulate != 0): the colour weights' gradient added straight into an existing gradient buffer
-extern "C" int ngan_to_image_bwd_pnbwd_acc(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
-                                           float* gw, float* workspace, long npix, int C, int Ncol, float slope, int accumulate, void* stream) {
-    NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
-    return to_image_bwd_impl(g, t, y, w, gc, gw, workspace, npix, C, Ncol, rnorm, slope, accumulate, stream);
-}
-
-static int to_image_bwd_impl(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
+template <typename T>
+static int to_image_bwd_impl(const float* g, const float* t, const T* x, const float* w, T* gx, float* gw,
                              float* workspace, long npix, int C, int Ncol, const float* rn, float slope, int accumulate, void* stream) {
     NGAN_REQUIRE(g && t && x && w && gx && gw && workspace, NGAN_ERR_ARG, "to_image_bwd: null pointer");
-    if (npix > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0 && !pow2_quads(C)) {
-        NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "to_image_bwd: accumulate is not available for C=%d", C);
-        return ngan::wide_to_image_bwd(g, t, x, w, gx, gw, npix, C, Ncol, rn, slope, (hipStream_t)stream);                       // wide.hip
-    }
+    if constexpr (is_f32<T>())
+        if (npix > 0 && Ncol >= 1 && Ncol <= 4 && C > 0 && C % 4 == 0 && !pow2_quads(C)) {
+            NGAN_REQUIRE(!accumulate, NGAN_ERR_SHAPE, "to_image_bwd: accumulate is not available for C=%d", C);
+            return ngan::wide_to_image_bwd(g, t, x, w, gx, gw, npix, C, Ncol, rn, slope, (hipStream_t)stream);                   // wide.hip
+        }
     NGAN_REQUIRE(npix > 0 && Ncol >= 1 && Ncol <= 4 && pow2_quads(C), NGAN_ERR_SHAPE, "to_image_bwd: npix=%ld C=%d Ncol=%d unsupported",
                  npix, C, Ncol);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = stream_blocks(npix, C / 4);
-#define CALL(QV) hipLaunchKernelGGL((to_image_bwd_kernel<QV>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope)
+#define CALL(QV) hipLaunchKernelGGL((to_image_bwd_kernel<T, QV>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope)
     Q_DISPATCH(CALL)
 #undef CALL
     int st = ngan::launch_status("ngan_to_image_bwd");
     if (st) return st;
     return ngan::reduce_partials_acc(workspace, nblk, C * Ncol, C * Ncol, gw, C * Ncol, nullptr, 1.0f, accumulate ? 1 : 0, s);
 }
+extern "C" int ngan_to_image_bwd(const float* g, const float* t, const float* x, const float* w, float* gx, float* gw,
+                                 float* workspace, long npix, int C, int Ncol, void* stream) {
+    return to_image_bwd_impl<float>(g, t, x, w, gx, gw, workspace, npix, C, Ncol, nullptr, 0.f, 0, stream);
+}
+extern "C" int ngan_to_image_bwd_pnbwd(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
+                                       float* gw, float* workspace, long npix, int C, int Ncol, float slope, void* stream) {
+    NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
+    return to_image_bwd_impl<float>(g, t, y, w, gc, gw, workspace, npix, C, Ncol, rnorm, slope, 0, stream);
+}
+// the same with gw += (accumulate != 0): the colour weights' gradient added straight into an existing gradient buffer
+extern "C" int ngan_to_image_bwd_pnbwd_acc(const float* g, const float* t, const float* y, const float* rnorm, const float* w, float* gc,
+                                           float* gw, float* workspace, long npix, int C, int Ncol, float slope, int accumulate, void* stream) {
+    NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
+    return to_image_bwd_impl<float>(g, t, y, w, gc, gw, workspace, npix, C, Ncol, rnorm, slope, accumulate, stream);
+}
+extern "C" int ngan_bf16_to_image_bwd(const float* g, const float* t, const ngan_bf16* x, const float* w, ngan_bf16* gx, float* gw,
+                                      float* workspace, long npix, int C, int Ncol, void* stream) {
+    return to_image_bwd_impl<__bf16>(g, t, BF(x), w, BFM(gx), gw, workspace, npix, C, Ncol, nullptr, 0.f, 0, stream);
+}
+extern "C" int ngan_bf16_to_image_bwd_pnbwd(const float* g, const float* t, const ngan_bf16* y, const float* rnorm, const float* w, ngan_bf16* gc,
+                                            float* gw, float* workspace, long npix, int C, int Ncol, float slope, void* stream) {
+    NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
+    return to_image_bwd_impl<__bf16>(g, t, BF(y), w, BFM(gc), gw, workspace, npix, C, Ncol, rnorm, slope, 0, stream);
+}
+extern "C" int ngan_bf16_to_image_bwd_pnbwd_acc(const float* g, const float* t, const ngan_bf16* y, const float* rnorm, const float* w,
+                                                ngan_bf16* gc, float* gw, float* workspace, long npix, int C, int Ncol, float slope, int accumulate,
+                                                void* stream) {
+    NGAN_REQUIRE(rnorm, NGAN_ERR_ARG, "to_image_bwd_pnbwd: null pointer");
+    return to_image_bwd_impl<__bf16>(g, t, BF(y), w, BFM(gc), gw, workspace, npix, C, Ncol, rnorm, slope, accumulate, stream);
+}
 
-#define RESAMPLE_API(NAME, KERNEL, TOTAL)                                                                      \
-    extern "C" int NAME(const float* a, float* o, int B, int h, int w, int C, void* stream) {                   \
-        NGAN_REQUIRE(a && o, NGAN_ERR_ARG, #NAME ": null pointer");                                            \
-        NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, #NAME ": bad dims %d %d %d %d", B, h, w, C); \
-        hipLaunchKernelGGL(KERNEL, dim3(ew_blocks(TOTAL)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);  \
-        return ngan::launch_status(#NAME);                                                                     \
-    }
-RESAMPLE_API(ngan_up2_fwd, up2_fwd_kernel, (long)B * 4 * h * w * C)
-static int launch_up2_adjoint_strip(const float* g, const float* yprev, const float* rn, float* o, int B, int h, int w, int C,
+template <typename T>
+static int up2_fwd_impl(const T* a, T* o, int B, int h, int w, int C, void* stream) {
+    NGAN_REQUIRE(a && o, NGAN_ERR_ARG, "ngan_up2_fwd: null pointer");
+    NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, "ngan_up2_fwd: bad dims %d %d %d %d", B, h, w, C);
+    hipLaunchKernelGGL(up2_fwd_kernel<T>, dim3(ew_blocks((long)B * 4 * h * w * C)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
+    return ngan::launch_status("ngan_up2_fwd");
+}
+extern "C" int ngan_up2_fwd(const float* a, float* o, int B, int h, int w, int C, void* stream) { return up2_fwd_impl<float>(a, o, B, h, w, C, stream); }
+extern "C" int ngan_bf16_up2_fwd(const ngan_bf16* a, ngan_bf16* o, int B, int h, int w, int C, void* stream) {
+    return up2_fwd_impl<__bf16>(BF(a), BFM(o), B, h, w, C, stream);
+}
+
+template <typename T>
+static int launch_up2_adjoint_strip(const T* g, const T* yprev, const float* rn, T* o, int B, int h, int w, int C,
                                     float slope, hipStream_t s) {
     const int Q = C / 4, YT = h < 16 ? h : 16;
     const dim3 grid(ceil_div(w, 256 / Q), ceil_div(h, YT), B), block(256);
 #define CALL(QV)                                                                                                                   \
-    if (yprev) hipLaunchKernelGGL((up2_adjoint_strip_kernel<QV, 1>), grid, block, 0, s, g, o, yprev, rn, h, w, slope, YT);           \
-    else hipLaunchKernelGGL((up2_adjoint_strip_kernel<QV, 0>), grid, block, 0, s, g, o, yprev, rn, h, w, slope, YT)
+    if (yprev) hipLaunchKernelGGL((up2_adjoint_strip_kernel<T, QV, 1>), grid, block, 0, s, g, o, yprev, rn, h, w, slope, YT);        \
+    else hipLaunchKernelGGL((up2_adjoint_strip_kernel<T, QV, 0>), grid, block, 0, s, g, o, yprev, rn, h, w, slope, YT)
     Q_DISPATCH(CALL)
 #undef CALL
     return ngan::launch_status("ngan_up2_adjoint(strip)");
+}
+
+template <typename T>
+static int up2_adjoint_impl(const T* a, T* o, int B, int h, int w, int C, void* stream) {
+    NGAN_REQUIRE(a && o, NGAN_ERR_ARG, "ngan_up2_adjoint: null pointer");
+    NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, "ngan_up2_adjoint: bad dims %d %d %d %d", B, h, w, C);
+    const long total = (long)B * h * w * C;
+    if (pow2_quads(C) && B < 65536) return launch_up2_adjoint_strip<T>(a, nullptr, nullptr, o, B, h, w, C, 0.f, (hipStream_t)stream);
+    if (C % 4 == 0) {
+        long nb = (total / 4 + 255) / 256;
+        hipLaunchKernelGGL(up2_adjoint_vec_kernel<T>, dim3((int)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
+    } else {
+        hipLaunchKernelGGL(up2_adjoint_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
+    }
+    return ngan::launch_status("ngan_up2_adjoint");
+}
+extern "C" int ngan_up2_adjoint(const float* a, float* o, int B, int h, int w, int C, void* stream) { return up2_adjoint_impl<float>(a, o, B, h, w, C, stream); }
+extern "C" int ngan_bf16_up2_adjoint(const ngan_bf16* a, ngan_bf16* o, int B, int h, int w, int C, void* stream) {
+    return up2_adjoint_impl<__bf16>(BF(a), BFM(o), B, h, w, C, stream);
 }
 
 extern "C" int ngan_up2_adjoint_pnbwd(const float* g, const float* yprev, const float* rnorm, float* o, int B, int h, int w, int C,
@@ -821,38 +917,54 @@ extern "C" int ngan_up2_adjoint_pnbwd(const float* g, const float* yprev, const 
         return st ? st : ngan::wide_pn_bwd(o, nullptr, nullptr, yprev, rnorm, o, (long)B * h * w, C, slope, (hipStream_t)stream);
     }
     NGAN_REQUIRE(B > 0 && B < 65536 && h > 0 && w > 0 && pow2_quads(C), NGAN_ERR_SHAPE, "ngan_up2_adjoint_pnbwd: bad dims %d %d %d %d", B, h, w, C);
-    return launch_up2_adjoint_strip(g, yprev, rnorm, o, B, h, w, C, slope, (hipStream_t)stream);
+    return launch_up2_adjoint_strip<float>(g, yprev, rnorm, o, B, h, w, C, slope, (hipStream_t)stream);
+}
+extern "C" int ngan_bf16_up2_adjoint_pnbwd(const ngan_bf16* g, const ngan_bf16* yprev, const float* rnorm, ngan_bf16* o, int B, int h, int w,
+                                           int C, float slope, void* stream) {
+    NGAN_REQUIRE(g && yprev && rnorm && o, NGAN_ERR_ARG, "ngan_bf16_up2_adjoint_pnbwd: null pointer");
+    NGAN_REQUIRE(B > 0 && B < 65536 && h > 0 && w > 0 && pow2_quads(C), NGAN_ERR_SHAPE, "ngan_bf16_up2_adjoint_pnbwd: bad dims %d %d %d %d", B, h, w, C);
+    return launch_up2_adjoint_strip<__bf16>(BF(g), BF(yprev), rnorm, BFM(o), B, h, w, C, slope, (hipStream_t)stream);
 }
 
-extern "C" int ngan_up2_adjoint(const float* a, float* o, int B, int h, int w, int C, void* stream) {
-    NGAN_REQUIRE(a && o, NGAN_ERR_ARG, "ngan_up2_adjoint: null pointer");
-    NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, "ngan_up2_adjoint: bad dims %d %d %d %d", B, h, w, C);
-    const long total = (long)B * h * w * C;
-    if (pow2_quads(C) && B < 65536) return launch_up2_adjoint_strip(a, nullptr, nullptr, o, B, h, w, C, 0.f, (hipStream_t)stream);
-    if (C % 4 == 0) {
-        long nb = (total / 4 + 255) / 256;
-        hipLaunchKernelGGL(up2_adjoint_vec_kernel, dim3((int)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
-    } else {
-        hipLaunchKernelGGL(up2_adjoint_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
-    }
-    return ngan::launch_status("ngan_up2_adjoint");
-}
-extern "C" int ngan_pool2_fwd(const float* a, float* o, int B, int h, int w, int C, void* stream) {
+template <typename T>
+static int pool2_fwd_impl(const T* a, T* o, int B, int h, int w, int C, void* stream) {
     NGAN_REQUIRE(a && o, NGAN_ERR_ARG, "ngan_pool2_fwd: null pointer");
     NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, "ngan_pool2_fwd: bad dims %d %d %d %d", B, h, w, C);
     const long total = (long)B * h * w * C;
     if (C % 4 == 0 && total / 4 < (1L << 31) - 256)
-        hipLaunchKernelGGL(pool2_fwd_v4_kernel, dim3(ceil_div(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, o, (int)(total / 4), h, w, C / 4);
+        hipLaunchKernelGGL(pool2_fwd_v4_kernel<T>, dim3(ceil_div(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, o, (int)(total / 4), h, w, C / 4);
     else
-        hipLaunchKernelGGL(pool2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
+        hipLaunchKernelGGL(pool2_fwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
     return ngan::launch_status("ngan_pool2_fwd");
 }
-RESAMPLE_API(ngan_pool2_adjoint, pool2_adjoint_kernel, (long)B * 4 * h * w * C)
+extern "C" int ngan_pool2_fwd(const float* a, float* o, int B, int h, int w, int C, void* stream) { return pool2_fwd_impl<float>(a, o, B, h, w, C, stream); }
+extern "C" int ngan_bf16_pool2_fwd(const ngan_bf16* a, ngan_bf16* o, int B, int h, int w, int C, void* stream) {
+    return pool2_fwd_impl<__bf16>(BF(a), BFM(o), B, h, w, C, stream);
+}
+
+template <typename T>
+static int pool2_adjoint_impl(const T* a, T* o, int B, int h, int w, int C, void* stream) {
+    NGAN_REQUIRE(a && o, NGAN_ERR_ARG, "ngan_pool2_adjoint: null pointer");
+    NGAN_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0, NGAN_ERR_SHAPE, "ngan_pool2_adjoint: bad dims %d %d %d %d", B, h, w, C);
+    hipLaunchKernelGGL(pool2_adjoint_kernel<T>, dim3(ew_blocks((long)B * 4 * h * w * C)), dim3(256), 0, (hipStream_t)stream, a, o, B, h, w, C);
+    return ngan::launch_status("ngan_pool2_adjoint");
+}
+extern "C" int ngan_pool2_adjoint(const float* a, float* o, int B, int h, int w, int C, void* stream) {
+    return pool2_adjoint_impl<float>(a, o, B, h, w, C, stream);
+}
+extern "C" int ngan_bf16_pool2_adjoint(const ngan_bf16* a, ngan_bf16* o, int B, int h, int w, int C, void* stream) {
+    return pool2_adjoint_impl<__bf16>(BF(a), BFM(o), B, h, w, C, stream);
+}
 
 extern "C" int ngan_lerp(const float* a, const float* b, const float* alpha, float* out, long n, void* stream) {
     NGAN_REQUIRE(a && b && alpha && out && n > 0, NGAN_ERR_ARG, "lerp: bad argument");
-    hipLaunchKernelGGL(lerp_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, out, n);
+    hipLaunchKernelGGL(lerp_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, out, n);
     return ngan::launch_status("ngan_lerp");
+}
+extern "C" int ngan_bf16_lerp(const ngan_bf16* a, const ngan_bf16* b, const float* alpha, ngan_bf16* out, long n, void* stream) {
+    NGAN_REQUIRE(a && b && alpha && out && n > 0, NGAN_ERR_ARG, "bf16_lerp: bad argument");
+    hipLaunchKernelGGL(lerp_kernel<__bf16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, BF(a), BF(b), alpha, BFM(out), n);
+    return ngan::launch_status("ngan_bf16_lerp");
 }
 
 extern "C" int ngan_axpby(const float* a, const float* b, float ca, float cb, float* out, long n, void* stream) {
@@ -863,8 +975,13 @@ extern "C" int ngan_axpby(const float* a, const float* b, float ca, float cb, fl
 
 extern "C" int ngan_fade_bwd(const float* g, const float* alpha, float* ga, float* gb, long n, void* stream) {
     NGAN_REQUIRE(g && alpha && ga && gb && n > 0, NGAN_ERR_ARG, "fade_bwd: bad argument");
-    hipLaunchKernelGGL(fade_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, alpha, ga, gb, n);
+    hipLaunchKernelGGL(fade_bwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, alpha, ga, gb, n);
     return ngan::launch_status("ngan_fade_bwd");
+}
+extern "C" int ngan_bf16_fade_bwd(const ngan_bf16* g, const float* alpha, ngan_bf16* ga, ngan_bf16* gb, long n, void* stream) {
+    NGAN_REQUIRE(g && alpha && ga && gb && n > 0, NGAN_ERR_ARG, "bf16_fade_bwd: bad argument");
+    hipLaunchKernelGGL(fade_bwd_kernel<__bf16>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, BF(g), alpha, BFM(ga), BFM(gb), n);
+    return ngan::launch_status("ngan_bf16_fade_bwd");
 }
 
 extern "C" int ngan_xhat(const float* real, const float* fake, const float* eps, float* out, int B, long n, void* stream) {

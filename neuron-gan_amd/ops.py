@@ -2,7 +2,10 @@
 (include/ngan.h) and closed under differentiation, so that the gradient-penalty double-backward through the
 critic (loss_functions.py:175 in the reference) runs entirely on those kernels.
 
-All tensors here are fp32, contiguous, channels-last: (B, H, W, C).  `models.py` converts at the module edges.
+All tensors here are contiguous, channels-last: (B, H, W, C), fp32 -- or, in the "bf16" mode (`set_conv_precision("bf16")`, precision
+code 5 of include/ngan.h), bf16 for every ACTIVATION tensor (layer outputs and the gradients w.r.t. them; images, norms, scalars,
+parameters and parameter gradients stay fp32).  An operator picks its entry point by the dtype of the activation tensors it is
+handed (`_k`), so the two storage modes share every autograd.Function below.  `models.py` converts at the module edges.
 
 Closure under differentiation (what the backward of each operator is built from):
     ConvLReLUPN   -> LReLUPNBwd, ConvDgrad, ConvWgrad, ChannelSum
@@ -105,7 +108,9 @@ class PNLink:
         self.fused = False
 # arithmetic of the 3x3 convolutions: "f32" = exact fp32 MFMA everywhere; "bf16x3" = few-channel layers on large images
 # use the split-bf16 kernels (3 bf16 MFMAs per product group, fp32 accumulate, ~1e-5 relative error), the rest stays fp32
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+# "bf16" = bf16 activation STORAGE + one bf16 MFMA per product group, fp32 accumulate / statistics / master weights: BASELINE.json's C2
+# configuration, an addition the reference does not have (train.py:136-144), with its own stated tolerance
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 5}
 _conv_precision = PRECISIONS[os.environ.get("NGAN_CONV_PRECISION", "f32")]
 
 
@@ -117,6 +122,19 @@ def set_conv_precision(name):
 
 def get_conv_precision():
     return [k for k, v in PRECISIONS.items() if v == _conv_precision][0]
+
+
+def act_dtype():
+    """storage type of activation tensors in the current mode (what the image -> feature operators allocate)"""
+    return torch.bfloat16 if _conv_precision == 5 else torch.float32
+
+
+def _k(name, *acts):
+    """the entry point for these activation tensors: `ngan_bf16_<op>` (include/ngan.h, last section) when they are bf16"""
+    for t in acts:
+        if t is not None and t.dtype == torch.bfloat16:
+            return "ngan_bf16_" + name[5:]
+    return name
 
 PIXELNORM_EPS = 1e-8  # models.py:105 of the reference
 
@@ -217,11 +235,11 @@ def _packed(weight, mode, scale, precision=0):
 
 
 def _c(t):
-    """contiguous fp32 view of a gradient tensor (autograd may hand us expanded / non-contiguous grads)"""
+    """contiguous view of a tensor (autograd may hand us expanded / non-contiguous grads); fp32, or bf16 activation storage"""
     if t is None:
         return None
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"the HIP path computes in fp32, got {t.dtype}")
+    if t.dtype != torch.float32 and t.dtype != torch.bfloat16:
+        raise RuntimeError(f"the HIP path stores tensors as fp32 (or bf16 activations in the bf16 mode), got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -275,6 +293,13 @@ def _pooled(x):
     return _resample("ngan_pool2_fwd", x, (b, h2 // 2, w2 // 2, c), b, h2 // 2, w2 // 2, c)
 
 
+def _bf16_prec(b, h, w, k, n, resample):
+    """precision code of a conv on bf16 activations: 5, or an error -- there is no fallback from bf16 storage to an fp32-storage kernel"""
+    if _C.conv3x3_algorithm(b, h, w, k, n, resample, 5) != 5:
+        raise RuntimeError(f"conv3x3 on bf16 activations takes 16 / 32 / 64 / 128 channels per call, got K={k}, N={n}")
+    return 5
+
+
 def _n_chunks(n):
     """Output-channel counts one kernel launch takes are 16, 32, 64 and 128 (include/ngan.h); any other multiple of 16 -- the
     reference's wide presets have 256-channel blocks, configs/config.py:87-98 -- is computed in chunks of those sizes, largest
@@ -296,7 +321,8 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=Non
     """y (and rnorm) = epilogue(conv3x3(resample(x), scale*W) + bias); keep_pooled: a list that receives the pooled input copy
     when one was made (`_pool_first`); pool_out: the consumer of y is an avg-pooled conv -- where the kernel can, it also writes
     the 2x2 average of y, which travels with y as `y._ngan_pooled` (same bits as the pooling pass it replaces)"""
-    if _pool_first(resample):
+    bf = x.dtype == torch.bfloat16
+    if _pool_first(resample) and not bf:
         side = _pooled_side(x)
         x = side if side is not None else _pooled(x)
         resample = RES_NONE
@@ -306,7 +332,7 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=Non
     cout, cin = weight.shape[0], weight.shape[1]
     if x.shape[3] != cin:
         raise RuntimeError(f"conv3x3: input has {x.shape[3]} channels, weight expects {cin}")
-    y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32)
+    y = torch.empty((b, h, w, cout), device=x.device, dtype=x.dtype)
     rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if epilogue else None
     chunks = _n_chunks(cout)
     if len(chunks) > 1:
@@ -316,7 +342,11 @@ def _run_conv(x, weight, bias, resample, scale, epilogue, slope, keep_pooled=Non
             yc, _ = _run_conv(x, weight[c0:c0 + n], bias[c0:c0 + n] if bias is not None else None, resample, scale, 0, 0.0)
             y[..., c0:c0 + n].copy_(yc)
         if epilogue:
-            _C.call("ngan_lrelu_pixelnorm_fwd", y, None, y, rn, b * h * w, cout, float(slope), PIXELNORM_EPS)
+            _C.call(_k("ngan_lrelu_pixelnorm_fwd", y), y, None, y, rn, b * h * w, cout, float(slope), PIXELNORM_EPS)
+        return y, rn
+    if bf:      # bf16 activation storage: one kernel family, resampling (pool / bilinear) while the tile is staged
+        _C.call("ngan_bf16_conv3x3_fwd", x, _packed(weight, 0, scale, _bf16_prec(b, h, w, cin, cout, resample)), bias, y, rn, None, None, None,
+                b, h, w, cin, cout, resample, epilogue, 0, float(slope), PIXELNORM_EPS)
         return y, rn
     prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
     packed = _packed(weight, 0, scale, prec)
@@ -346,24 +376,45 @@ def _run_dgrad(g, weight, resample, scale, link=None):
         # wide layer: the input gradient in chunks of its channels (the kernel's N), unfused; the producer's PixelNorm backward as
         # a launch of its own over all the channels
         oh, ow = (2 * h, 2 * w) if resample == RES_POOL2 else (h, w)
-        full = torch.empty((b, oh, ow, cin), device=g.device, dtype=torch.float32)
+        full = torch.empty((b, oh, ow, cin), device=g.device, dtype=g.dtype)
         for c0, n in chunks:
             full[..., c0:c0 + n].copy_(_run_dgrad(g, weight[:, c0:c0 + n], RES_POOL2 if resample == RES_POOL2 else RES_NONE, scale))
         if resample == RES_UP2:
-            gx = torch.empty((b, h // 2, w // 2, cin), device=g.device, dtype=torch.float32)
+            gx = torch.empty((b, h // 2, w // 2, cin), device=g.device, dtype=g.dtype)
             if link is not None:
-                _C.call("ngan_up2_adjoint_pnbwd", full, ay, arn, gx, b, h // 2, w // 2, cin, slope)
+                _C.call(_k("ngan_up2_adjoint_pnbwd", full), full, ay, arn, gx, b, h // 2, w // 2, cin, slope)
             else:
-                _C.call("ngan_up2_adjoint", full, gx, b, h // 2, w // 2, cin)
+                _C.call(_k("ngan_up2_adjoint", full), full, gx, b, h // 2, w // 2, cin)
             return gx
         if link is not None:
             if tuple(ay.shape) != tuple(full.shape):
                 raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(full.shape)}")
-            _C.call("ngan_lrelu_pixelnorm_bwd", full, None, ay, arn, full, b * oh * ow, cin, slope)
+            _C.call(_k("ngan_lrelu_pixelnorm_bwd", full), full, None, ay, arn, full, b * oh * ow, cin, slope)
         return full
+    epi = EPI_PN_BWD if link is not None else EPI_NONE
+    if g.dtype == torch.bfloat16:
+        packed = _packed(weight, 1, scale, _bf16_prec(b, h, w, cout, cin, 0))
+        if link is not None and ay.dtype != g.dtype:
+            raise RuntimeError("PixelNorm hand-off: producer output and gradient differ in storage type")
+        if resample == RES_UP2:
+            gfull = torch.empty((b, h, w, cin), device=g.device, dtype=g.dtype)
+            _C.call("ngan_bf16_conv3x3_fwd", g, packed, None, gfull, None, None, None, None, b, h, w, cout, cin, 0, EPI_NONE, 0, 0.0, 0.0)
+            gx = torch.empty((b, h // 2, w // 2, cin), device=g.device, dtype=g.dtype)
+            if link is not None:
+                if tuple(ay.shape) != tuple(gx.shape):
+                    raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(gx.shape)}")
+                _C.call("ngan_bf16_up2_adjoint_pnbwd", gfull, ay, arn, gx, b, h // 2, w // 2, cin, slope)
+            else:
+                _C.call("ngan_bf16_up2_adjoint", gfull, gx, b, h // 2, w // 2, cin)
+            return gx
+        pool = resample == RES_POOL2
+        gx = torch.empty((b, 2 * h, 2 * w, cin) if pool else (b, h, w, cin), device=g.device, dtype=g.dtype)
+        if link is not None and tuple(ay.shape) != tuple(gx.shape):
+            raise RuntimeError(f"PixelNorm hand-off: producer output {tuple(ay.shape)} is not the conv input {tuple(gx.shape)}")
+        _C.call("ngan_bf16_conv3x3_fwd", g, packed, None, gx, None, ay, arn, None, b, h, w, cout, cin, 0, epi, 1 if pool else 0, slope, 0.0)
+        return gx
     prec = _C.conv3x3_algorithm(b, h, w, cout, cin, 0, _conv_precision)
     packed = _packed(weight, 1, scale, prec)
-    epi = EPI_PN_BWD if link is not None else EPI_NONE
     if resample == RES_POOL2:
         gx = torch.empty((b, 2 * h, 2 * w, cin), device=g.device, dtype=torch.float32)
         if link is not None and tuple(ay.shape) != tuple(gx.shape):
@@ -436,21 +487,32 @@ def flush_wgrad():
 def _run_wgrad(x, g, resample, scale, accumulate_into=None, role=0, pooled=None):
     """role: 0 = weight gradient of a forward conv node, 1 = of an input-gradient node (ConvDgrad.backward); see flush_wgrad.
     pooled: the 2x2-averaged copy of x the forward pass made, if it kept one (`_pool_first`)"""
-    if _pool_first(resample):
+    bf = g.dtype == torch.bfloat16
+    if x.dtype != g.dtype:
+        raise RuntimeError(f"conv3x3 wgrad: input is {x.dtype}, output gradient is {g.dtype}")
+    if _pool_first(resample) and not bf:
         x = pooled if pooled is not None else _pooled(x)
         resample = RES_NONE
     b, h, w, cout = g.shape
     cin = x.shape[3]
     gw = accumulate_into if accumulate_into is not None else torch.empty((cout, cin, 3, 3), device=g.device, dtype=torch.float32)
     ws = torch.empty(_C.wgrad_workspace_bytes(b, h, w, cin, cout) // 4, device=g.device, dtype=torch.float32)
+    prec = 5 if bf else _conv_precision
+    if bf and prec == 5 and (cin % 16 or cout % 16):
+        raise RuntimeError(f"conv3x3 wgrad on bf16 activations: Cin={cin}, Cout={cout} must be multiples of 16")
+
+    def launch(accumulate):
+        if bf:      # bf16 x and g, fp32 slabs and gradient (include/ngan.h: ngan_bf16_conv3x3_wgrad)
+            _C.call("ngan_bf16_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), accumulate)
+        else:
+            _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), accumulate, prec)
     if accumulate_into is not None and _defer_depth > 0:
-        _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 2, _conv_precision)
-        plan = _C.wgrad_plan(b, h, w, cin, cout, _conv_precision)
+        launch(2)
+        plan = _C.wgrad_plan(b, h, w, cin, cout, prec)
         e = _pending.setdefault(gw.data_ptr(), dict(gw=gw, plan=plan, cin=cin, sources=[]))
         e["sources"].append((ws, plan[0], float(scale), role))
         return gw
-    _C.call("ngan_conv3x3_wgrad", x, g, gw, ws, b, h, w, cin, cout, resample, float(scale), 1 if accumulate_into is not None else 0,
-            _conv_precision)
+    launch(1 if accumulate_into is not None else 0)
     return gw
 
 
@@ -474,14 +536,14 @@ def _channel_sum(g, into=None):
     out = into if into is not None else torch.empty(c, device=g.device, dtype=torch.float32)
     ws = torch.empty(1024 * c, device=g.device, dtype=torch.float32)
     if into is not None and (c // 4) & (c // 4 - 1) == 0 and c <= 256:
-        _C.call("ngan_channel_sum_acc", g, out, ws, npix, c, 1.0, 1)
+        _C.call(_k("ngan_channel_sum_acc", g), g, out, ws, npix, c, 1.0, 1)
         return out
     if into is not None:
         tmp = torch.empty(c, device=g.device, dtype=torch.float32)
-        _C.call("ngan_channel_sum", g, tmp, ws, npix, c, 1.0)
+        _C.call(_k("ngan_channel_sum", g), g, tmp, ws, npix, c, 1.0)
         into.add_(tmp)
         return into
-    _C.call("ngan_channel_sum", g, out, ws, npix, c, 1.0)
+    _C.call(_k("ngan_channel_sum", g), g, out, ws, npix, c, 1.0)
     return out
 
 
@@ -577,12 +639,16 @@ class ConvLReLUPNToImage(Function):
         b, h, w = _conv_out_hw(x, resample)
         cout, cin = weight.shape[0], weight.shape[1]
         keep = bool(keep) and any(ctx.needs_input_grad)
-        y = torch.empty((b, h, w, cout), device=x.device, dtype=torch.float32) if keep else None
+        y = torch.empty((b, h, w, cout), device=x.device, dtype=x.dtype) if keep else None
         rn = torch.empty((b, h, w), device=x.device, dtype=torch.float32) if keep else None
         t = torch.empty((b, h, w, 1), device=x.device, dtype=torch.float32)
-        prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
-        _C.call("ngan_conv3x3_fwd_ex", x, _packed(weight, 0, scale, prec), bias, y, rn, w_img.detach().reshape(-1), None, t,
-                b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, float(slope), PIXELNORM_EPS, prec, 0)
+        if x.dtype == torch.bfloat16:
+            _C.call("ngan_bf16_conv3x3_fwd", x, _packed(weight, 0, scale, _bf16_prec(b, h, w, cin, cout, resample)), bias, y, rn,
+                    w_img.detach().reshape(-1), None, t, b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, float(slope), PIXELNORM_EPS)
+        else:
+            prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
+            _C.call("ngan_conv3x3_fwd_ex", x, _packed(weight, 0, scale, prec), bias, y, rn, w_img.detach().reshape(-1), None, t,
+                    b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, float(slope), PIXELNORM_EPS, prec, 0)
         if keep:
             ctx.save_for_backward(x, weight, y, rn, t, w_img)
         ctx.has_bias = bias is not None
@@ -604,11 +670,11 @@ class ConvLReLUPNToImage(Function):
         gc = torch.empty_like(y)      # ToImage backward and the LeakyReLU->PixelNorm backward in one pass over y
         if (_small_grads_in_place and ctx.needs_input_grad[3] and _accumulates_in_place(w_img) and (c // 4) & (c // 4 - 1) == 0
                 and c <= 256):
-            _C.call("ngan_to_image_bwd_pnbwd_acc", _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, w_img.grad, ws, npix, c, 1, float(slope), 1)
+            _C.call(_k("ngan_to_image_bwd_pnbwd_acc", y), _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, w_img.grad, ws, npix, c, 1, float(slope), 1)
             gw_img = None             # w_img.grad += ... inside the reduction
         else:
             gw_img = torch.empty_like(w_img)
-            _C.call("ngan_to_image_bwd_pnbwd", _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, gw_img, ws, npix, c, 1, float(slope))
+            _C.call(_k("ngan_to_image_bwd_pnbwd", y), _c(gt), t, y, rn, w_img.detach().reshape(1, c), gc, gw_img, ws, npix, c, 1, float(slope))
             if not ctx.needs_input_grad[3]:
                 gw_img = None         # a frozen colour weight: computed by the fused pass, handed to nobody
         gx, gw, gb = _conv_backward_tail(ctx, x, weight, gc, resample, scale, ctx.in_link, ctx.has_bias)
@@ -621,7 +687,7 @@ def to_image_fusable(x, weight, w_img, resample):
         return False
     b, h, w = _conv_out_hw(x, resample)
     cout, cin = weight.shape[0], weight.shape[1]
-    prec = _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
+    prec = 5 if x.dtype == torch.bfloat16 else _C.conv3x3_algorithm(b, h, w, cin, cout, resample, _conv_precision)
     return _C.conv3x3_epilogue_fused(b, h, w, cin, cout, resample, EPI_TO_IMAGE, 0, prec)
 
 
@@ -724,7 +790,7 @@ class LReLUPN(Function):
         ch = c.shape[-1]
         y = torch.empty_like(c)
         rn = torch.empty(c.shape[:-1], device=c.device, dtype=torch.float32)
-        _C.call("ngan_lrelu_pixelnorm_fwd", c, bias, y, rn, c.numel() // ch, ch, float(slope), PIXELNORM_EPS)
+        _C.call(_k("ngan_lrelu_pixelnorm_fwd", c), c, bias, y, rn, c.numel() // ch, ch, float(slope), PIXELNORM_EPS)
         ctx.save_for_backward(y, rn)
         ctx.slope = slope
         ctx.has_bias = bias is not None
@@ -762,7 +828,9 @@ class LReLUPNBwd(Function):
         gy, gr = _c(gy), _c(gr)
         ch = y.shape[-1]
         gc = torch.empty_like(y)
-        _C.call("ngan_lrelu_pixelnorm_bwd2", gy, _c(gy2), gr, y, rn, gc, y.numel() // ch, ch, float(slope))
+        if gy.dtype != y.dtype:
+            gy = gy.to(y.dtype)
+        _C.call(_k("ngan_lrelu_pixelnorm_bwd2", y), gy, _c(gy2), gr, y, rn, gc, y.numel() // ch, ch, float(slope))
         if gy2 is None:            # (gy2 only comes from a no-grad pass, which records no graph: see ConvLReLUPN.backward)
             ctx.save_for_backward(gy, y, rn)
         ctx.had_gr = gr is not None
@@ -782,7 +850,7 @@ class LReLUPNBwd(Function):
         ggy = torch.empty_like(y)
         gy_out = torch.empty_like(y)
         gr_out = torch.empty_like(rn)
-        _C.call("ngan_lrelu_pixelnorm_bwdbwd", h, gy, y, rn, ggy, gy_out, gr_out, y.numel() // ch, ch, float(ctx.slope))
+        _C.call(_k("ngan_lrelu_pixelnorm_bwdbwd", y), h, gy, y, rn, ggy, gy_out, gr_out, y.numel() // ch, ch, float(ctx.slope))
         pad = (None,) * (ctx.n_in - 5)
         if ctx.stash is not None and ctx.stash.pending is None:
             ctx.stash.pending = gy_out          # picked up by the producing layer's backward (GradStash)
@@ -804,8 +872,8 @@ class FromImage(Function):
         x = _c(x)
         b, h, wd = _from_image_out_hw(x, pool)
         c, ncol = w.shape[0], w.shape[1]
-        y = torch.empty((b, h, wd, c), device=x.device, dtype=torch.float32)
-        _C.call("ngan_from_image_fwd", x, w.detach().reshape(c, ncol), bias, y, b, h, wd, ncol, c, int(pool))
+        y = torch.empty((b, h, wd, c), device=x.device, dtype=act_dtype())
+        _C.call(_k("ngan_from_image_fwd", y), x, w.detach().reshape(c, ncol), bias, y, b, h, wd, ncol, c, int(pool))
         ctx.save_for_backward(x, w)
         ctx.pool = pool
         ctx.has_bias = bias is not None
@@ -827,7 +895,7 @@ class FromImage(Function):
                 gg = _c(g)
                 b, h, wd, _ = gg.shape
                 ws = torch.empty(1024 * c * (ncol + 1), device=gg.device, dtype=torch.float32)
-                _C.call("ngan_from_image_dw_acc", x, gg, w.grad, bias.grad if want_b else None, ws, b, h, wd, ncol, c, int(ctx.pool), 3)
+                _C.call(_k("ngan_from_image_dw_acc", gg), x, gg, w.grad, bias.grad if want_b else None, ws, b, h, wd, ncol, c, int(ctx.pool), 3)
             else:
                 gw, gb = FromImageDw.apply(x, g, ctx.pool, tuple(w.shape))
                 if not ctx.needs_input_grad[1]:
@@ -841,8 +909,9 @@ _first_block_allowed = _diag_env("NGAN_FIRST_BLOCK", "1") != "0"      # A/B swit
 
 
 def first_block_fusable(x, w_from, w_conv):
-    """can FirstBlock take FromImage -> conv3x3 -> LeakyReLU -> PixelNorm?  (one colour channel, 16 or 32 conv outputs)"""
-    return (_first_block_allowed and x.shape[-1] == 1 and w_from.shape[1] == 1 and w_conv.shape[0] in (16, 32)
+    """can FirstBlock take FromImage -> conv3x3 -> LeakyReLU -> PixelNorm?  (one colour channel, 16 or 32 conv outputs; fp32 storage:
+    the folded kernels write fp32 activations, the bf16 mode runs the two layers as they are)"""
+    return (_first_block_allowed and _conv_precision != 5 and x.shape[-1] == 1 and w_from.shape[1] == 1 and w_conv.shape[0] in (16, 32)
             and w_conv.shape[1] <= 64 and x.shape[0] * x.shape[1] < 65536)
 
 
@@ -886,7 +955,7 @@ class FirstBlock(Function):
             gc = _c(gy)         # the consumer's input-gradient kernel already applied this layer's LeakyReLU->PixelNorm backward
         else:
             gc = torch.empty_like(y)
-            _C.call("ngan_lrelu_pixelnorm_bwd", _c(gy), None, y, rn, gc, y.numel() // n, n, float(slope))
+            _C.call(_k("ngan_lrelu_pixelnorm_bwd", y), _c(gy), None, y, rn, gc, y.numel() // n, n, float(slope))
         dev = y.device
         in_place = False
         gw = gwf = gbf = gb = None
@@ -925,7 +994,7 @@ class FromImageDx(Function):
         b, h, wd, c = g.shape
         ncol = w.shape[1]
         gx = torch.empty((b, 2 * h, 2 * wd, ncol) if pool else (b, h, wd, ncol), device=g.device, dtype=torch.float32)
-        _C.call("ngan_from_image_dx", g, w.detach().reshape(c, ncol), gx, b, h, wd, ncol, c, int(pool))
+        _C.call(_k("ngan_from_image_dx", g), g, w.detach().reshape(c, ncol), gx, b, h, wd, ncol, c, int(pool))
         ctx.save_for_backward(g, w)
         ctx.pool = pool
         return gx
@@ -941,7 +1010,7 @@ class FromImageDx(Function):
                 hh = _c(h)
                 b, hgt, wd, _ = g.shape
                 ws = torch.empty(1024 * c * (ncol + 1), device=g.device, dtype=torch.float32)
-                _C.call("ngan_from_image_dw_acc", hh, g, w.grad, None, ws, b, hgt, wd, ncol, c, int(ctx.pool), 1)
+                _C.call(_k("ngan_from_image_dw_acc", g), hh, g, w.grad, None, ws, b, hgt, wd, ncol, c, int(ctx.pool), 1)
             else:
                 gw = FromImageDw.apply(h, g, ctx.pool, tuple(w.shape))[0]
         return gg, gw, None
@@ -956,7 +1025,7 @@ class FromImageDw(Function):
         gw = torch.empty(w_shape, device=g.device, dtype=torch.float32)
         gb = torch.empty(c, device=g.device, dtype=torch.float32)
         ws = torch.empty(1024 * c * (ncol + 1), device=g.device, dtype=torch.float32)
-        _C.call("ngan_from_image_dw", x, g, gw, gb, ws, b, h, wd, ncol, c, int(pool))
+        _C.call(_k("ngan_from_image_dw", g), x, g, gw, gb, ws, b, h, wd, ncol, c, int(pool))
         ctx.save_for_backward(x, g)
         ctx.pool = pool
         return gw, gb
@@ -985,7 +1054,7 @@ class ToImage(Function):
         x = _c(x)
         ncol, c = w.shape[0], w.shape[1]
         t = torch.empty(x.shape[:-1] + (ncol,), device=x.device, dtype=torch.float32)
-        _C.call("ngan_to_image_fwd", x, w.detach().reshape(ncol, c), t, x.numel() // c, c, ncol)
+        _C.call(_k("ngan_to_image_fwd", x), x, w.detach().reshape(ncol, c), t, x.numel() // c, c, ncol)
         ctx.save_for_backward(x, w, t)
         return t
 
@@ -998,7 +1067,7 @@ class ToImage(Function):
         gx = torch.empty_like(x)
         gw = torch.empty_like(w)
         ws = torch.empty(1024 * c * ncol, device=x.device, dtype=torch.float32)
-        _C.call("ngan_to_image_bwd", g, t, x, w.detach().reshape(ncol, c), gx, gw, ws, x.numel() // c, c, ncol)
+        _C.call(_k("ngan_to_image_bwd", x), g, t, x, w.detach().reshape(ncol, c), gx, gw, ws, x.numel() // c, c, ncol)
         return gx, gw
 
 
@@ -1006,8 +1075,8 @@ class ToImage(Function):
 # resampling and fade-in (linear pairs)
 # ---------------------------------------------------------------------------------------------------------
 def _resample(name, x, out_shape, b, h, w, c):
-    out = torch.empty(out_shape, device=x.device, dtype=torch.float32)
-    _C.call(name, x, out, b, h, w, c)
+    out = torch.empty(out_shape, device=x.device, dtype=x.dtype)
+    _C.call(_k(name, x), x, out, b, h, w, c)
     return out
 
 
@@ -1066,7 +1135,9 @@ class Lerp(Function):
     def forward(ctx, a, b, alpha):
         a, b = _c(a), _c(b)
         out = torch.empty_like(a)
-        _C.call("ngan_lerp", a, b, alpha, out, a.numel())
+        if a.dtype != b.dtype:
+            raise RuntimeError(f"lerp: operands differ in storage type ({a.dtype}, {b.dtype})")
+        _C.call(_k("ngan_lerp", a), a, b, alpha, out, a.numel())
         ctx.save_for_backward(alpha)
         return out
 
@@ -1082,7 +1153,7 @@ class FadeBwd(Function):
     def forward(ctx, g, alpha):
         g = _c(g)
         ga, gb = torch.empty_like(g), torch.empty_like(g)
-        _C.call("ngan_fade_bwd", g, alpha, ga, gb, g.numel())
+        _C.call(_k("ngan_fade_bwd", g), g, alpha, ga, gb, g.numel())
         ctx.save_for_backward(alpha)
         return ga, gb
 
@@ -1117,9 +1188,9 @@ class LinearLReLUPN(Function):
         b, k = z.shape
         s2 = size * size
         c = weight.shape[0] // s2
-        y = torch.empty((b, size, size, c), device=z.device, dtype=torch.float32)
+        y = torch.empty((b, size, size, c), device=z.device, dtype=act_dtype())
         rn = torch.empty((b, size, size), device=z.device, dtype=torch.float32)
-        _C.call("ngan_linear_lrelu_pn_fwd", z, weight.detach(), y, rn, b, k, s2, c, float(scale), float(slope), PIXELNORM_EPS)
+        _C.call(_k("ngan_linear_lrelu_pn_fwd", y), z, weight.detach(), y, rn, b, k, s2, c, float(scale), float(slope), PIXELNORM_EPS)
         ctx.save_for_backward(z, weight, y, rn)
         ctx.cfg = (s2, c, scale, slope)
         ctx.mark_non_differentiable(rn)
@@ -1142,20 +1213,20 @@ class LinearLReLUPN(Function):
             gc = gy       # the consuming conv's input-gradient kernel already applied the LeakyReLU->PixelNorm backward
         else:
             gc = torch.empty_like(y)
-            _C.call("ngan_lrelu_pixelnorm_bwd", gy, None, y, rn, gc, b * s2, c, float(slope))
+            _C.call(_k("ngan_lrelu_pixelnorm_bwd", y), gy, None, y, rn, gc, b * s2, c, float(slope))
         gz = gw = None
         if ctx.needs_input_grad[1]:
             if linear_grad_sink is not None:
                 linear_grad_sink(z, gc, weight, s2, c, scale)      # gradient is formed later from the gathered factors
             elif _accumulates_in_place(weight) and k % 16 == 0 and k <= 512:
                 # weight.grad += ... inside the kernel: no 67 MB temporary and no separate 200 MB accumulate pass
-                _C.call("ngan_linear_wgrad_acc", z, gc, weight.grad, b, k, s2, c, float(scale), 1)
+                _C.call(_k("ngan_linear_wgrad_acc", gc), z, gc, weight.grad, b, k, s2, c, float(scale), 1)
             else:
                 gw = torch.empty_like(weight)
-                _C.call("ngan_linear_wgrad", z, gc, gw, b, k, s2, c, float(scale))
+                _C.call(_k("ngan_linear_wgrad", gc), z, gc, gw, b, k, s2, c, float(scale))
         if ctx.needs_input_grad[0]:
             gz = torch.empty_like(z)
-            _C.call("ngan_linear_dgrad", gc, weight.detach(), gz, b, k, s2, c, float(scale))
+            _C.call(_k("ngan_linear_dgrad", gc), gc, weight.detach(), gz, b, k, s2, c, float(scale))
         return (gz, gw, None, None, None) + (None,) * (ctx.n_in - 5)
 
 
@@ -1169,7 +1240,7 @@ class FinalDot(Function):
         c = y.shape[3]
         s2 = y.shape[1] * y.shape[2]
         out = torch.empty((b, 1), device=y.device, dtype=torch.float32)
-        _C.call("ngan_final_dot_fwd", y, weight.detach(), bias, out, b, s2, c, float(scale))
+        _C.call(_k("ngan_final_dot_fwd", y), y, weight.detach(), bias, out, b, s2, c, float(scale))
         ctx.save_for_backward(y, weight)
         ctx.scale = scale
         ctx.has_bias = bias is not None
@@ -1179,7 +1250,7 @@ class FinalDot(Function):
     @staticmethod
     def backward(ctx, go):
         y, weight = ctx.saved_tensors
-        gy = FinalDotDx.apply(go, weight, ctx.scale, tuple(y.shape)) if ctx.needs_input_grad[0] else None
+        gy = FinalDotDx.apply(go, weight, ctx.scale, tuple(y.shape), y.dtype) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and _param_grads_wanted():
             bias = ctx.bias_param
@@ -1187,7 +1258,7 @@ class FinalDot(Function):
             if (_small_grads_in_place and ctx.needs_input_grad[1] and _accumulates_in_place(weight)
                     and (not want_b or (bias is not None and _accumulates_in_place(bias)))):
                 b, hh, ww, c = y.shape
-                _C.call("ngan_final_dot_dw_acc", y, _c(go), weight.grad, bias.grad if want_b else None, b, hh * ww, c, float(ctx.scale), 3)
+                _C.call(_k("ngan_final_dot_dw_acc", y), y, _c(go), weight.grad, bias.grad if want_b else None, b, hh * ww, c, float(ctx.scale), 3)
             else:
                 gw, gb = FinalDotDw.apply(y, go, ctx.scale, tuple(weight.shape))
                 if not ctx.needs_input_grad[1]:
@@ -1199,11 +1270,11 @@ class FinalDot(Function):
 
 class FinalDotDx(Function):
     @staticmethod
-    def forward(ctx, go, weight, scale, y_shape):
+    def forward(ctx, go, weight, scale, y_shape, y_dtype=torch.float32):
         go = _c(go)
         b, h, w, c = y_shape
-        gy = torch.empty(y_shape, device=go.device, dtype=torch.float32)
-        _C.call("ngan_final_dot_dx", go, weight.detach(), gy, b, h * w, c, float(scale))
+        gy = torch.empty(y_shape, device=go.device, dtype=y_dtype)
+        _C.call(_k("ngan_final_dot_dx", gy), go, weight.detach(), gy, b, h * w, c, float(scale))
         ctx.save_for_backward(go, weight)
         ctx.scale = scale
         return gy
@@ -1217,10 +1288,10 @@ class FinalDotDx(Function):
             if _small_grads_in_place and _accumulates_in_place(weight):
                 hh = _c(h)
                 b, hgt, wd, c = hh.shape
-                _C.call("ngan_final_dot_dw_acc", hh, go, weight.grad, None, b, hgt * wd, c, float(ctx.scale), 1)
+                _C.call(_k("ngan_final_dot_dw_acc", hh), hh, go, weight.grad, None, b, hgt * wd, c, float(ctx.scale), 1)
             else:
                 gw = FinalDotDw.apply(h, go, ctx.scale, tuple(weight.shape))[0]
-        return ggo, gw, None, None
+        return ggo, gw, None, None, None
 
 
 class FinalDotDw(Function):
@@ -1230,7 +1301,7 @@ class FinalDotDw(Function):
         b, h, w, c = y.shape
         gw = torch.empty(w_shape, device=y.device, dtype=torch.float32)
         gb = torch.empty(1, device=y.device, dtype=torch.float32)
-        _C.call("ngan_final_dot_dw", y, go, gw, gb, b, h * w, c, float(scale))
+        _C.call(_k("ngan_final_dot_dw", y), y, go, gw, gb, b, h * w, c, float(scale))
         ctx.save_for_backward(y, go)
         ctx.scale = scale
         return gw, gb
@@ -1242,7 +1313,7 @@ class FinalDotDw(Function):
         if hw is not None:
             hw = _c(hw)
             if ctx.needs_input_grad[0]:
-                gy = FinalDotDx.apply(go, hw, ctx.scale, tuple(y.shape))
+                gy = FinalDotDx.apply(go, hw, ctx.scale, tuple(y.shape), y.dtype)
             if ctx.needs_input_grad[1]:
                 ggo = FinalDot.apply(y, hw, None, ctx.scale)
         if hb is not None and ctx.needs_input_grad[1]:

@@ -123,7 +123,7 @@ class FusedAdam:
         if stem_factors is not None:
             z, gc, s2, c, scale = stem_factors
             n = f.params[0].numel()
-            _C.call("ngan_linear_wgrad_adam", z, gc, f.flat[:n], f.exp_avg[:n], f.exp_avg_sq[:n], f.seg_step[:1], self.hyper, self.hyper.numel(),
+            _C.call(ops._k("ngan_linear_wgrad_adam", gc), z, gc, f.flat[:n], f.exp_avg[:n], f.exp_avg_sq[:n], f.seg_step[:1], self.hyper, self.hyper.numel(),
                     z.shape[0], z.shape[1], s2, c, float(scale))
         self.repack()
 
@@ -156,7 +156,7 @@ class StemGradExchange:
         self.factors = None      # (z, gc, s2, c, scale) over ALL ranks' samples after finish(): what FusedAdam.step(stem_factors=) takes
         self._gathered = {}      # gather buffers per factor shape: captured Adam launches read them, so they must not move
         self.wgrad_fn = wgrad_fn or (lambda zs, gs, out, n, k, s2, c, scale:
-                                     _C.call("ngan_linear_wgrad", zs, gs, out, n, k, s2, c, float(scale)))
+                                     _C.call(ops._k("ngan_linear_wgrad", gs), zs, gs, out, n, k, s2, c, float(scale)))
 
     def sink(self, z, gc, weight, s2, c, scale):
         assert weight is self.weight

@@ -220,6 +220,54 @@ def full_fixture(models, config, name):
     out.update(z_d=z_d.numpy(), z_gp=z_gp.numpy(), z_g=z_g.numpy(), eps=eps.numpy())
     out["real_cs"] = np.array([float(x.double().sum()), float(x.double().abs().sum())])
     out["meta"] = np.array([res, alpha, 16, 512, batch, 1e-4], dtype=np.float64)
+    # A SECOND iteration on the same reals (round 4): the next four draws of the same RNG stream (order z_d, z_gp, eps, z_g; the
+    # forward / backward passes consume none), through the weights and Adam state the first iteration left.  The first Adam step
+    # moves every weight by ~lr * sign(g), which amplifies rounding-level gradient differences into individual flipped steps; the
+    # second step's scalars and critic gradients say what is left of that one iteration later.  (Written after everything above, so
+    # the keys of the earlier rounds keep their values bit for bit.)
+    z_d2 = latent(batch, 512)
+    z_gp2 = latent(batch, 512)
+    eps2 = torch.rand(batch, 1, 1, 1)
+    z_g2 = latent(batch, 512)
+    cap2 = {}
+    scal2, L2 = ref_step(G, D, oG, oD, x, z_d2, z_gp2, eps2, z_g2, capture=cap2)
+    out["s2/scalars"] = np.array([scal2[k] for k in ("D_loss", "score_real", "score_fake", "GP", "G_loss")], dtype=np.float64)
+    out["s2/grad_norms"] = L2["norms"].detach().numpy()
+    out["s2/G_loss_pre"] = cap2["G_loss_pre"]
+    for k, v in cap2.items():
+        if k.startswith(("Dgrad/", "Ggrad/")):
+            flat = v.reshape(-1)
+            out["s2/cs/" + k] = np.array([float(v.astype(np.float64).sum()), float(np.abs(v.astype(np.float64)).sum())])
+            out["s2/sl/" + k] = flat[:96].copy()
+            out["s2/mx/" + k] = np.array([float(np.argmax(np.abs(flat))), float(flat[np.argmax(np.abs(flat))]), float(np.abs(flat).max())])
+    out.update({"s2/z_d": z_d2.numpy(), "s2/z_gp": z_gp2.numpy(), "s2/z_g": z_g2.numpy(), "s2/eps": eps2.numpy()})
+    # The same two iterations with the reference modules in fp64 (same weights, reals and draws, cast): how far the reference's OWN fp32
+    # arithmetic is from the exact answer one update later.  The first Adam step is ~lr * sign(g), so gradient elements at rounding
+    # level take the other sign in another arithmetic and the second iteration sees slightly different weights: this spread is a
+    # property of the algorithm, and it is the yardstick for the second-iteration test (tests/test_gpu_models.py).
+    torch.manual_seed(1)
+    G64 = models.Generator_PG(config.N_gen_features, image_size_init=16)
+    D64 = models.Discriminator_PG(config.N_dis_features, image_size_init=16)
+    G64.to(torch.device("cpu"), torch.float64)
+    D64.to(torch.device("cpu"), torch.float64)
+    if res != 16:
+        G64.set_resolution(res, alpha)
+        D64.set_resolution(res, alpha)
+    oD64 = torch.optim.Adam(D64.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    oG64 = torch.optim.Adam(G64.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    d = lambda t: t.double()
+    ref_step(G64, D64, oG64, oD64, d(x), d(z_d), d(z_gp), d(eps), d(z_g))
+    cap64 = {}
+    scal64, L64 = ref_step(G64, D64, oG64, oD64, d(x), d(z_d2), d(z_gp2), d(eps2), d(z_g2), capture=cap64)
+    out["s2/f64/scalars"] = np.array([scal64[k] for k in ("D_loss", "score_real", "score_fake", "GP", "G_loss")], dtype=np.float64)
+    out["s2/f64/grad_norms"] = L64["norms"].detach().numpy()
+    for k, v in cap64.items():
+        if k.startswith(("Dgrad/", "Ggrad/")):
+            flat = v.reshape(-1)
+            i32 = int(out["s2/mx/" + k][0])                 # the SAME element the fp32 pin names, plus the tensor's own max-norm
+            out["s2/f64/cs/" + k] = np.array([float(v.sum()), float(np.abs(v).sum())])
+            out["s2/f64/sl/" + k] = flat[:96].copy()
+            out["s2/f64/mx/" + k] = np.array([float(i32), float(flat[i32]), float(np.abs(flat).max())])
     if name in SURVEY_PINS:
         pins = np.array(SURVEY_PINS[name])
         rel = np.abs(out["scalars"] - pins) / np.abs(pins)

@@ -10,6 +10,12 @@ under double-backward so the gradient penalty sees them too):
   fp8 convs      additionally the operands of every 3x3 / full-extent convolution (activations and weights, per-tensor scaled to the
                  e4m3 range; gradients in e5m2) are rounded to fp8 and the convolution's result to bf16 (bf16 accumulation is
                  modelled by ONE final rounding, which flatters it)
+  bf16 mode      (round 4) what the product's "bf16" mode (precision code 5, csrc/conv3x3_bf16.hip) rounds: bf16 storage as above, PLUS
+                 the 3x3 convolutions' weights rounded to bf16 with the equalised-LR scale folded in first (fp32 masters, straight-
+                 through gradient: the weight gradient is an fp32 sum of bf16 x bf16 products), PLUS one rounding of a resampled
+                 conv input (the kernel blends the 2x2 / bilinear taps in fp32 and stores the blend in its bf16 LDS tile).
+                 Accumulation, PixelNorm statistics, biases and the 1x1 / linear / head layers stay fp32.  This row is where the
+                 mode's own test tolerances come from (tests/test_gpu_bf16.py).
 Reported: relative error of the quantities the north star bounds at 1e-3 (losses, D(x), |grad D|), and of the parameter gradients.
 """
 import os
@@ -52,6 +58,8 @@ def quantize(x, kind):
 def install(mode):
     """patch the oracle's primitives; returns a function that restores them"""
     saved = {k: getattr(O, k) for k in ("pixel_norm", "scaled_conv", "from_image", "to_image")}
+    modes_known = ("f32", "bf16", "bf16mode", "fp8")
+    assert mode in modes_known, mode
     if mode == "f32":
         return lambda: None
     store = lambda t: Round.apply(t, "bf16", "bf16")
@@ -60,12 +68,21 @@ def install(mode):
         return store(saved["pixel_norm"](x, eps))
 
     def scaled_conv(x, w, b, slope, padding):
+        if mode == "bf16mode" and w.shape[2] == 3:
+            fan_in = w.shape[1] * w.shape[2] * w.shape[3]
+            sc = O.weight_scale(fan_in, slope)
+            wq = Round.apply(w * sc, "bf16", "none") / sc           # the packing kernel rounds scale * W; its gradient is not rounded
+            return saved["scaled_conv"](x, wq, b, slope, padding)
         if mode == "fp8":
             x, w = Round.apply(x, "e4m3", "e5m2"), Round.apply(w, "e4m3", "e5m2")
             return store(saved["scaled_conv"](x, w, b, slope, padding))
         return saved["scaled_conv"](x, w, b, slope, padding)
 
     O.pixel_norm, O.scaled_conv = pixel_norm, scaled_conv
+    if mode == "bf16mode":
+        saved["up2"], saved["pool2"] = O.up2, O.pool2
+        O.up2 = lambda x: store(saved["up2"](x))
+        O.pool2 = lambda x: store(saved["pool2"](x))
     O.from_image = lambda x, w, b: store(saved["from_image"](x, w, b))
     O.to_image = lambda x, w: store(saved["to_image"](x, w))
 
@@ -93,7 +110,7 @@ def one_step(pg, pd, spec, x, z1, z2, eps, z3):
 
 def budget(name, pg, pd, spec, x, z1, z2, eps, z3):
     out = {}
-    for mode in ("f32", "bf16", "fp8"):
+    for mode in ("f32", "bf16", "bf16mode", "fp8"):
         restore = install(mode)
         try:
             out[mode] = one_step(pg, pd, spec, x, z1, z2, eps, z3)
@@ -101,9 +118,10 @@ def budget(name, pg, pd, spec, x, z1, z2, eps, z3):
             restore()
     ref = out["f32"]
     rows = {}
-    for mode in ("bf16", "fp8"):
+    for mode in ("bf16", "bf16mode", "fp8"):
         sc, norms, dg, gg = out[mode]
         r = {k: abs(sc[k] - ref[0][k]) / max(abs(ref[0][k]), 1e-12) for k in sc}
+        r["scalars / max scalar"] = max(abs(sc[k] - ref[0][k]) for k in sc) / max(abs(v) for v in ref[0].values())
         r["|grad D|"] = float(((norms - ref[1]).abs() / ref[1].abs()).max())
         r["D grads (rel L2)"] = float((dg - ref[2]).norm() / ref[2].norm())
         r["G grads (rel L2)"] = float((gg - ref[3]).norm() / ref[3].norm())
@@ -138,6 +156,8 @@ def full_case(res, alpha, batch):
 
 CASES = {"small 16x16 warmed (|grad D| = O(1))": lambda: small_case("small_res16_warm"),
          "small 16x16 fade-in warmed": lambda: small_case("small_res16_fade_warm"),
+         "small 4x4 fresh": lambda: small_case("small_fresh4"), "small 8x8 init": lambda: small_case("small_res8_init"),
+         "small 8x8 warmed": lambda: small_case("small_res8_warm"), "small 16x16 fade-in init": lambda: small_case("small_res16_fade_init"),
          "C1 shape: full widths, 16x16, batch 16": lambda: full_case(16, 1.0, 16),
          "C2 shape: full widths, 64x64 alpha 0.5, batch 16": lambda: full_case(64, 0.5, 16)}
 
@@ -148,7 +168,7 @@ def main():
         rows = budget(name, *make())
         print(name)
         for mode, r in rows.items():
-            label = {"bf16": "bf16 storage", "fp8": "fp8 convs + bf16 accumulate/storage"}[mode]
+            label = {"bf16": "bf16 storage", "bf16mode": "bf16 mode (storage + bf16 conv weights)", "fp8": "fp8 convs + bf16 accumulate/storage"}[mode]
             print(f"    {label:38s} " + "  ".join(f"{k} {v:.1e}" for k, v in r.items()))
     return 0
 

@@ -101,6 +101,127 @@ def test_two_rank_gradient_exchange_equals_big_batch(fixture):
     mp.spawn(_worker, args=(2, _free_port(), fixture), nprocs=2, join=True)
 
 
+def _replica_worker(rank, world, port, fixture):
+    """Three iterations of PGGANTrainer.replay's SEGMENT SEQUENCE -- [critic forward/backward] -> exchange -> [critic Adam, generator
+    forward/backward] -> exchange -> [generator Adam] -- over gloo with different data on each rank.  The three segments are stand-ins
+    (the CPU oracle's gradients written into the trainer's flat .grad views; a torch restatement of the fused Adam over the flat
+    buffers, grad_scale included) because the kernels need a GPU; everything between them is the product's code: replay(), the
+    graph cache keyed by input shape, _exchange(), exchange_gradients(), the 1/world factor in the optimiser's hyper-parameters."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import load_package
+        from conftest import load_golden, split_state
+        from oracle import pggan_oracle as O
+        pkg = load_package()
+        torch.set_num_threads(2)
+        fix = load_golden(fixture)
+        res, alpha, init, latent, batch, lr = fix["meta"]
+        res, init, latent = int(res), int(init), int(latent)
+        spec = O.NetSpec(image_size_init=init, slope=0.2, alpha=float(alpha))
+        own = [dist.new_group([r]) for r in range(world)][rank]           # a one-rank group: the single-process reference
+        b = 2                                                             # per-rank batch
+
+        def build(group):
+            G = pkg.models.Generator_PG([32, 16, 16], image_size_init=init, latent_dim=latent)
+            D = pkg.models.Discriminator_PG([16, 16, 32], image_size_init=init)
+            if res != init:
+                G.set_resolution(res, float(alpha))
+                D.set_resolution(res, float(alpha))
+            G.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "G/").items()})
+            D.load_state_dict({k: torch.from_numpy(v) for k, v in split_state(fix, "D/").items()})
+            tr = pkg.train.PGGANTrainer(G, D, learning_rate=1e-3, process_group=group, fused_stem=False)
+            return G, D, tr
+
+        def draws(it, r):           # what rank r sees in iteration it (every rank can rebuild every rank's batch)
+            g = torch.Generator().manual_seed(1000 * it + r)
+            z = [O.sample_latent_vec((b, latent), generator=g) for _ in range(3)]
+            return torch.rand(b, 1, res, res, generator=g) * 2 - 1, z[0], z[1], torch.rand(b, 1, 1, 1, generator=g), z[2]
+
+        def ref_adam(flat, opt):
+            lr_, b1, b2, eps_, gscale = opt.hyper_host[:5]
+            for i, (p, off, a) in enumerate(zip(flat.params, flat.offsets, flat.active_host)):
+                if not a:
+                    continue
+                n = p.numel()
+                flat.seg_step[i] += 1
+                t = float(flat.seg_step[i])
+                g = flat.grad[off:off + n] * gscale
+                m, v, w = flat.exp_avg[off:off + n], flat.exp_avg_sq[off:off + n], flat.flat[off:off + n]
+                m.lerp_(g, 1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                w.addcdiv_(m, (v.sqrt() / (1 - b2 ** t) ** 0.5).add_(eps_), value=-lr_ / (1 - b1 ** t))
+
+        class Segment:                     # what a captured HIP graph is to replay(): something with .replay()
+            def __init__(self, fn):
+                self.fn = fn
+
+            def replay(self):
+                self.fn()
+
+        def install(tr, G, D, batch_of, n_samples):
+            """batch_of(): the (real, z_d, z_gp, eps, z_g) the segments compute on (set per iteration through `cur`)"""
+            pg = dict(G.named_parameters())
+            pd = dict(D.named_parameters())
+            pd["alpha"] = D.alpha
+
+            def seg_a():
+                tr.flat_d.zero_grad()
+                x, z1, z2, e, _ = batch_of()
+                loss, _, _ = O.d_w_loss(pg, spec, pd, spec, x, z1, 0.001)
+                gp = O.grad_penalty(pg, spec, pd, spec, x, z2, e, 10.0)
+                tr.flat_g.zero_grad()          # (the oracle's detached generator passes leave nothing, its graph might)
+                (loss + gp).backward(inputs=[p for p in D.parameters()])
+
+            def seg_b():
+                ref_adam(tr.flat_d, tr.opt_d)
+                tr.flat_g.zero_grad()
+                _, _, _, _, z3 = batch_of()
+                O.g_w_loss(pg, spec, pd, spec, z3).backward(inputs=[p for p in G.parameters()])
+
+            def seg_c():
+                ref_adam(tr.flat_g, tr.opt_g)
+
+            static_real = torch.zeros(n_samples, 1, res, res)
+            tr._graphs[tuple(static_real.shape)] = ([Segment(seg_a), Segment(seg_b), Segment(seg_c)], static_real, {}, None, [], (False, False))
+
+        cur = {}
+        G, D, tr = build(None)
+        assert tr.world == world and tr.opt_d.hyper_host[4] == 1.0 / world
+        install(tr, G, D, lambda: cur["mine"], b)
+        Gr, Dr, ref = build(own)
+        assert ref.world == 1
+        install(ref, Gr, Dr, lambda: cur["all"], world * b)
+        start = [ref.flat_d.flat.clone(), ref.flat_g.flat.clone()]
+        for it in range(3):
+            per_rank = [draws(it, r) for r in range(world)]
+            cur["mine"] = per_rank[rank]
+            cur["all"] = tuple(torch.cat([d[i] for d in per_rank]) for i in range(5))
+            tr.replay(cur["mine"][0])
+            ref.replay(cur["all"][0])
+        # replicas: bit-identical parameters and Adam state on both ranks after three updates ...
+        for flat in (tr.flat_d, tr.flat_g):
+            for buf in (flat.flat, flat.exp_avg, flat.exp_avg_sq, flat.seg_step):
+                other = buf.clone()
+                dist.broadcast(other, src=0)
+                assert torch.equal(other, buf), "replicas diverged"
+        # ... and equal to ONE rank training on the concatenated batches (SURVEY.md 8e: N ranks x b == 1 rank x N b up to summation order)
+        for flat, fr, was in ((tr.flat_d, ref.flat_d, start[0]), (tr.flat_g, ref.flat_g, start[1])):
+            assert float((fr.flat - was).abs().max()) > 1e-3         # (three steps of lr 1e-3 did move the weights)
+            assert float((flat.flat - fr.flat).abs().max()) < 2e-5, float((flat.flat - fr.flat).abs().max())
+        assert [int(v) for v in tr.flat_d.seg_step.tolist()] == [3 * int(a) for a in tr.flat_d.active_host]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixture", ["small_res16_fade_warm"])
+def test_replayed_segments_with_exchanges_keep_two_replicas_identical(fixture):
+    mp.spawn(_replica_worker, args=(2, _free_port(), fixture), nprocs=2, join=True)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus N` is the driver's multi-GPU command: with no launcher environment the script itself must start
     the N rank processes (before anything touches a GPU) and rank 0 must print one JSON line whose n_gpus is N and whose observed

@@ -178,6 +178,70 @@ def test_full_width_pins(ngan, name, conv_precision):
         assert abs(float(np.abs(g.astype(np.float64)).sum()) - cs[1]) < 2e-2 * cs[1], ("G", k)
 
 
+def check_slices_s2(fix, key, g, tol):
+    """as check_slices, on the second iteration's pins (`s2/` keys)"""
+    flat = np.asarray(g, np.float64).reshape(-1)
+    sl, mx = fix["s2/sl/" + key].astype(np.float64), fix["s2/mx/" + key]
+    scale = float(mx[2])
+    worst = max(float(np.abs(flat[:sl.size] - sl).max()), abs(flat[int(mx[0])] - mx[1])) / scale
+    return worst < tol, worst
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_full_width_second_iteration(ngan, name, conv_precision):
+    """What follows the first update (round-3 review: the only statement about it was the 2e-2 slack on the post-Adam generator
+    checksums).  Two iterations of the step driver on the fixture's reals with the reference's draws (RNG order z_d, z_gp, eps, z_g per
+    iteration, oracle/make_golden.py), then the SECOND iteration's scalars, |grad D| and critic gradients against the reference's.
+
+    It does matter, and not through anything this repo does: the first Adam step moves every weight by ~lr * sign(g), so a gradient
+    element at rounding level takes the other sign in another arithmetic.  Measured on the CPU oracle alone (tools/step2_sensitivity.py,
+    profiles/r04_step2_sensitivity.txt): torch fp32 against torch fp64 -- the same algorithm -- are 3.8e-3 apart on the second
+    iteration's |grad D| and 2.3e-2 on its critic gradient elements at C2 (the fixtures carry that fp64 run as `s2/f64/*`), and noise of
+    2e-4 of a tensor's maximum on the first iteration's gradients (inside the north star's 1e-3) moves them by 1.1e-2 / 5.7e-2.  A
+    1e-3 pin on the second iteration is therefore not a property any fp32 implementation has.  The bounds here are what the kernels
+    measured with margin (worst over C1-C5: |grad D| 5.9e-3, critic gradient elements 5.2e-3, scalars 2.4e-3) and stay below that
+    sensitivity: scalars 5e-3, |grad D| 1e-2, critic gradient elements 1e-2 of the tensor's max-norm (split-bf16 biases 2e-2),
+    generator checksums 3e-2; and the result must be no further from the fp64 answer than 1.5e-2 on |grad D|."""
+    fix = load_golden(name)
+    res, alpha, init, latent, batch, lr = fix["meta"]
+    res, batch = int(res), int(batch)
+    cfg = ngan.config
+    torch.manual_seed(1)
+    G = ngan.models.Generator_PG(cfg.N_gen_features, image_size_init=16)
+    D = ngan.models.Discriminator_PG(cfg.N_dis_features, image_size_init=16)
+    if res != 16:
+        G.set_resolution(res, float(alpha))
+        D.set_resolution(res, float(alpha))
+    torch.manual_seed(123)
+    x = (torch.rand(batch, 1, res, res) * 2 - 1).to(DEV)
+    G.to(DEV)
+    D.to(DEV)
+    t = lambda k: torch.from_numpy(fix[k]).to(DEV)
+    tr = ngan.train.PGGANTrainer(G, D, learning_rate=float(lr), beta1=0.5, grad_pen_lambda=10.0, drift_epsilon=0.001)
+    tr.train_iteration(x, t("z_d"), t("z_gp"), t("eps"), t("z_g"))
+    sd = tr.d_step(x, z_d=t("s2/z_d"), z_gp=t("s2/z_gp"), eps=t("s2/eps"))
+    cur_d = {id(p): n for n, p in D.named_parameters()}
+    dgrads = {cur_d[id(p)]: p.grad.detach().cpu().numpy().copy() for p, a in zip(tr.flat_d.params, tr.flat_d.active_host) if a}
+    norms = tr.gp_loss.last_grad_norms.cpu().numpy()
+    sg = tr.g_step(x, z=t("s2/z_g"))
+    tr.materialize_stem_grad()
+    cur_g = {id(p): n for n, p in G.named_parameters()}
+    ggrads = {cur_g[id(p)]: p.grad.detach().cpu().numpy().copy() for p, a in zip(tr.flat_g.params, tr.flat_g.active_host) if a}
+    scal = np.array([float(sd["D_loss"]), float(sd["score_real"]), float(sd["score_fake"]), float(sd["D_grad_pen"]), float(sg["G_loss"])])
+    want = fix["s2/scalars"]
+    assert np.allclose(scal, want, rtol=5e-3, atol=5e-5), (scal, want)
+    assert rel(norms, fix["s2/grad_norms"]) < 1e-2, rel(norms, fix["s2/grad_norms"])
+    assert rel(norms, fix["s2/f64/grad_norms"]) < 1.5e-2, rel(norms, fix["s2/f64/grad_norms"])
+    worst = {}
+    for k, g in dgrads.items():
+        ok, w = check_slices_s2(fix, "Dgrad/" + k, g, 2e-2 if (conv_precision != "f32" and k.endswith(".bias")) else 1e-2)
+        worst[k] = w
+        assert ok, ("D step 2", k, w)
+    for k, g in ggrads.items():
+        cs = fix["s2/cs/Ggrad/" + k]
+        assert abs(float(np.abs(g.astype(np.float64)).sum()) - cs[1]) < 3e-2 * cs[1], ("G step 2", k)
+
+
 @pytest.mark.parametrize("n_colors,res,alpha,widths", [(3, 16, 0.5, None), (3, 16, 1.0, None), (1, 32, 1.0, None),
                                                        # widths that are not multiples of 16: the reference's presets 0004-0006 end in
                                                        # 8-channel blocks (configs/config.py:86-92); zero-padded contraction path

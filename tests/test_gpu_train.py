@@ -375,3 +375,89 @@ def test_eager_iterations_do_not_leak_device_memory(ngan):
         torch.cuda.synchronize()
         seen.append(torch.cuda.memory_allocated())
     assert seen[-1] <= seen[3], seen
+
+
+def test_pooled_side_output_is_consumed_and_never_stale(ngan):
+    """The 2x2-averaged copy a Winograd conv writes next to its output travels to the pooled conv of the next block as an attribute of
+    the tensor object (ops._run_conv / ops._pooled_side).  (a) On the headline critic (512x512, fp32) it IS consumed: one feature-map
+    pooling pass is left in a forward pass (behind the 64-channel block, whose producer is not a Winograd kernel); with the side output
+    switched off there are four.  (b) A copy whose tensor was written after the producer stored it is not used."""
+    ops, C = ngan.ops, ngan._C
+    ops.set_conv_precision("f32")
+
+    class Count:
+        def __init__(self):
+            self.n = 0
+
+        def wants(self, name, args):
+            if name == "ngan_pool2_fwd" and args[-1] >= 16:        # (the one-channel image pool of the first block is not a feature map)
+                self.n += 1
+            return False
+
+        def add(self, *a):
+            pass
+
+    torch.manual_seed(1)
+    D = ngan.models.Discriminator_PG(ngan.config.N_dis_features, image_size_init=16)
+    D.set_resolution(512, 1.0)
+    D.to(DEV)
+    x = torch.rand(16, 1, 512, 512, device=DEV) * 2 - 1          # the headline batch: at 64x64 it still gives the 256 tiles a Winograd launch wants
+    counts = []
+    for allowed in (True, False):
+        ops._pool_out_allowed = allowed
+        probe = Count()
+        C.set_probe(probe)
+        try:
+            with torch.no_grad(), ops.first_order_only():
+                score = D(x)
+        finally:
+            C.set_probe(None)
+            ops._pool_out_allowed = True
+        counts.append((probe.n, score.clone()))
+    assert counts[0][0] == 1 and counts[1][0] == 4, [c[0] for c in counts]
+    assert torch.equal(counts[0][1], counts[1][1])                  # same bits either way
+    # (b) staleness
+    w = torch.randn(16, 16, 3, 3, device=DEV)
+    xin = torch.randn(2, 128, 256, 16, device=DEV)
+    y, _ = ops._run_conv(xin, w, None, 0, 0.1, 1, 0.2, pool_out=True)
+    side = ops._pooled_side(y)
+    assert side is not None and tuple(side.shape) == (2, 64, 128, 16)
+    assert torch.equal(side, ops._pooled(y))
+    y.mul_(2.0)
+    assert ops._pooled_side(y) is None                             # written since: the copy is stale and a pooling pass runs instead
+    assert ops._pooled_side(y.detach()) is None                    # another tensor object: no copy travels with it
+
+
+def test_capture_survives_garbage_left_by_earlier_trainers(ngan):
+    """Regression for the abort on record (gpurun_out/r03_a_tests.log: `Fatal Python error: Aborted` under "Garbage-collecting" during
+    the third capture() of a process).  A dead trainer whose captured graphs sit in a reference cycle is left behind, the collector is
+    set to run at every allocation, and a further capture() must neither abort nor be disturbed: capture() collects BEFORE the capture
+    begins and keeps the cyclic collector off until it ends (PGGANTrainer.capture; which finalizer is the dangerous one:
+    tools/gc_capture_probe.py, profiles/r04_gc_capture_probe.txt).  Run once; no repeat loop."""
+    import gc
+    fix = load_golden("small_res16_warm")
+    import test_gpu_models as M
+    real = torch.from_numpy(fix["real"]).to(DEV)
+
+    def make():
+        G, D = M.build_small(ngan, fix)
+        return ngan.train.PGGANTrainer(G, D, device_latents=True)
+
+    for _ in range(2):                       # two dead trainers, each holding its graphs in a cycle only the collector can free
+        t = make()
+        t.capture(real)
+        t.replay(real)
+        t.me = t
+        del t
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        t3 = make()
+        t3.capture(real)                     # the third capture of the process
+        assert gc.isenabled()                # ... and the collector is back on afterwards
+        t3.replay(real)
+        torch.cuda.synchronize()
+    finally:
+        gc.set_threshold(*old)
+    gc.collect()
+    assert all(torch.isfinite(p).all() for p in t3.G.parameters())
