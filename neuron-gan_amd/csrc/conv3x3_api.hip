@@ -40,7 +40,7 @@ extern "C" int ngan_conv3x3_pooled_output(int B, int H, int W, int K, int N, int
 extern "C" int ngan_conv3x3_epilogue_fused(int B, int H, int W, int K, int N, int resample, int epilogue, int out_mode, int precision) {
     if (epilogue == EPI_NONE || epilogue == EPI_LRELU_PN) return 1;
     if (precision == 5)      // the bf16 kernel has every epilogue built in (ToImage: plain input, plain store)
-        return ngan::conv3x3_bf16_elements(K, N) > 0 && (epilogue == EPI_PN_BWD ? resample == 0 : (resample == 0 && out_mode == 0)) ? 1 : 0;
+        return ngan::conv3x3_bf16_elements(K, N) > 0 && (epilogue == EPI_PN_BWD ? resample == 0 : (resample == 0 && out_mode == 0 && N <= 32)) ? 1 : 0;
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const bool persist = persist_eligible(B, H, W, K, N, resample);
     if (epilogue == EPI_TO_IMAGE) return persist && resample == 0 && out_mode == 0 ? 1 : 0;

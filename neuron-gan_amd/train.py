@@ -564,10 +564,17 @@ class PGGANTrainer:
         # is part of the capture) is what _on_comm_stream takes care of.  Both reproduced case by case: tools/capture_event_probe.py.
         mode = ops._diag_env("NGAN_CAPTURE_MODE", "") or ("thread_local" if self._comm_stream is not None else "global")
         # No cyclic garbage collection while a capture is active: a collection that happens to start inside the captured region runs
-        # the finalizers of whatever cyclic garbage earlier code left behind (graphs of a previous stage or trainer, events, tensors
-        # of released graph pools) on the capturing thread, and HIP aborts the process for some of those calls during a global-mode
-        # capture (seen once: `Fatal Python error: Aborted` under "Garbage-collecting" in the third capture of a process).
-        # torch.cuda.graph() no longer collects on entry by itself.  Collect now, then keep the collector off until the capture ends.
+        # the finalizers of whatever cyclic garbage earlier code left behind on the capturing thread.  The one that must not run there
+        # is torch.cuda.CUDAGraph's: destroying an EARLIER captured graph (hipGraphExecDestroy / hipGraphDestroy and the release of its
+        # private pool) while a global-mode capture is active fails with hipErrorStreamCaptureUnsupported, which a destructor can only
+        # turn into std::terminate -- the `Fatal Python error: Aborted` under "Garbage-collecting" of gpurun_out/r03_a_tests.log (third
+        # capture of a process: the first two trainers' graphs were cyclic garbage by then).  Events, tensors of a released graph pool
+        # and tensors recorded on a second stream are harmless (tools/gc_capture_probe.py, one case per child process:
+        # profiles/r04_gc_capture_probe.txt).  torch.cuda.graph() no longer collects on entry by itself.  Collect now, then keep the
+        # collector off until the capture ends.  This concerns GLOBAL-mode captures (one GPU, no process group); with an RCCL group
+        # the captures run in thread_local mode, where a graph destroyed on ANOTHER thread is legal -- the collector could still pick the
+        # capturing thread, so it is kept off in both modes (gc.disable() is process-wide, for the few milliseconds of a capture).
+        # Regression: tests/test_gpu_train.py::test_capture_survives_garbage_left_by_earlier_trainers.
         import gc
         gc.collect()
         gc_was_enabled = gc.isenabled()
