@@ -49,6 +49,12 @@ __device__ __forceinline__ void st4bf(__amdgpu_buffer_rsrc_t rs, unsigned off, f
 // tiles (N = 16, 32: the large-image layers).  NS = true (N = 64, 128): the waves split the OUTPUT tiles (N / 64 each), every wave
 // contracts all PGT pixel groups -- a weight fragment is fetched by exactly one wave of the workgroup, and the per-pixel sums of the
 // PixelNorm epilogues cross the waves through 4 KB of LDS.  NARROW: 16-pixel-wide tiles for images at most 16 wide.
+// Tried and rejected (round 4): a PERSISTENT form of the pixel-split instances (a band of tiles per workgroup, tile t + 1's staging loads
+// requested before tile t's MFMAs, weights fetched once).  Inside a tile loop the compiler hoists every tile-invariant index -- staging
+// slots, LDS addresses, tap offsets -- into loop-carried registers: 133 instead of 61 for 16 -> 16 (three workgroups per CU instead of
+// eight); capping the registers (launch bounds, lane coordinates behind an opaque barrier) made it spill 44 - 125 registers to scratch
+// instead of recomputing, and the 16 -> 16 forward went from 63 to 152 us.  The one-tile-per-workgroup form below stays: its remedy for
+// "bytes in flight per CU" is occupancy (64 registers, 14 KB of LDS: eight workgroups per CU).
 template <int K, int N, int PGT, bool NS, bool NARROW>
 // (the 16 -> 16 instances fit 64 registers: eight workgroups per CU instead of four -- the kernel is bound by memory round trips per
 // resident workgroup, not by issue: 303 VALU + 20 MFMA instructions per wave and tile, 6 % VALU-busy, PMC profiles/r04_pmc_bf16_1616.txt)
@@ -267,15 +273,24 @@ __global__ __launch_bounds__(256, (!NS && K == 16 && N == 16) ? 8 : 1) void conv
             ss[pg] = sum_rows4(s);
         }
         xsum(ss, PGW);
+        // the norms of a wave's pixel groups leave in ONE store instruction: every k-group row q holds all the sums, row q stores group q
+        // (one 64-byte run per group; four separate instructions with three quarters of their lanes switched off cost 4x the issue slots)
         const __amdgpu_buffer_rsrc_t rn_rs = rsrc_of(a.rn ? a.rn + img_pix : nullptr, a.rn ? (unsigned)(H * W) * 4u : 0u);
+        float rn_val = 0.f;
+        unsigned rn_off = BF16_OOB;
+        static_assert(PGW <= 4, "one k-group row per pixel group");
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg) {
             const float m = ss[pg] * inv_n + a.eps;
             const float inv = __builtin_amdgcn_rsqf(m);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) v[pg][j] = f4scale(v[pg][j], inv);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m * inv), rn_rs, (valid[pg] && q == 0 && wave == (NS ? 0 : wave)) ? poff[pg] * 4u : BF16_OOB, 0, 0);
+            if (q == pg) {
+                rn_val = m * inv;
+                rn_off = valid[pg] ? poff[pg] * 4u : BF16_OOB;
+            }
         }
+        if (!NS || wave == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rn_val), rn_rs, rn_off, 0, 0);
         if (epi == EPI_TO_IMAGE) {                     // (N = 16 / 32 instances only: the launcher refuses it for NS)
 #pragma unroll
             for (int pg = 0; pg < PGW; ++pg) {
