@@ -56,7 +56,7 @@ G_WIDTHS = [128, 64, 32, 32, 16, 16]
 D_WIDTHS = [16, 16, 32, 32, 64, 128]
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (about 6.3 TB/s is achievable with a float4 copy)
-PROFILE_TAG = "r03"            # profiles/<tag>_traffic_<precision>.json holds the PMC traffic per kernel
+PROFILE_TAG = "r04"            # profiles/<tag>_traffic_<precision>.json holds the PMC traffic per kernel
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -104,6 +104,26 @@ template <> __device__ __forceinline__ void sta4<float>(float* p, float4 v) { *r
 template <> __device__ __forceinline__ void sta4<__bf16>(__bf16* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
 }
+// V float4s = 4 V consecutive channels per lane.  V = 2 exists for bf16 storage: one 16-byte access per lane instead of 8 bytes -- the
+// per-pixel kernels are pure streams, and with 2-byte elements a 4-channel access puts half as many bytes in flight per wave
+template <typename T, int V> __device__ __forceinline__ void ldav(const T* p, float4 (&out)[V]) {
+    if constexpr (V == 2 && sizeof(T) == 2) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        out[0] = make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+        out[1] = make_float4(bf16_lo(u.z), bf16_hi(u.z), bf16_lo(u.w), bf16_hi(u.w));
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) out[i] = lda4(p + 4 * i);
+    }
+}
+template <typename T, int V> __device__ __forceinline__ void stav(T* p, const float4 (&v)[V]) {
+    if constexpr (V == 2 && sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16(v[0].x, v[0].y), pack_bf16(v[0].z, v[0].w), pack_bf16(v[1].x, v[1].y), pack_bf16(v[1].z, v[1].w));
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) sta4(p + 4 * i, v[i]);
+    }
+}
 template <typename T> __device__ __forceinline__ float lda1(const T* p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void sta1(T* p, float v) { *p = (T)v; }
 

@@ -9,7 +9,8 @@ namespace {
 
 __device__ __forceinline__ float lrelu_mask(float y, float slope) { return y > 0.f ? 1.f : slope; }
 
-template <typename T, int LPP>
+// V float4s (4 V consecutive channels) per lane: 1, or 2 for bf16 storage (16-byte accesses; ngan_common.h)
+template <typename T, int LPP, int V>
 __global__ __launch_bounds__(256) void pn_fwd_kernel(const T* __restrict__ c, const float* __restrict__ bias,
                                                      T* __restrict__ y, float* __restrict__ rn, long npix, int C,
                                                      float slope, float eps) {
@@ -17,19 +18,28 @@ __global__ __launch_bounds__(256) void pn_fwd_kernel(const T* __restrict__ c, co
     const long pix = gid / LPP;
     const int sub = (int)(gid % LPP);
     const bool ok = pix < npix;
-    float4 v = ok ? lda4(c + pix * C + sub * 4) : f4zero();
-    if (bias) v = f4add(v, ld4(bias + sub * 4));
-    v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
-    v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
-    const float ss = group_sum<LPP>(f4dot(v, v));
+    float4 v[V];
+    if (ok) ldav<T, V>(c + pix * C + sub * 4 * V, v);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        if (!ok) v[i] = f4zero();
+        if (bias) v[i] = f4add(v[i], ld4(bias + (sub * V + i) * 4));
+        v[i].x = v[i].x > 0.f ? v[i].x : slope * v[i].x; v[i].y = v[i].y > 0.f ? v[i].y : slope * v[i].y;
+        v[i].z = v[i].z > 0.f ? v[i].z : slope * v[i].z; v[i].w = v[i].w > 0.f ? v[i].w : slope * v[i].w;
+        d += f4dot(v[i], v[i]);
+    }
+    const float ss = group_sum<LPP>(d);
     const float r = sqrtf(ss / (float)C + eps);
     if (ok) {
-        sta4(y + pix * C + sub * 4, f4scale(v, 1.0f / r));
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = f4scale(v[i], 1.0f / r);
+        stav<T, V>(y + pix * C + sub * 4 * V, v);
         if (sub == 0) rn[pix] = r;
     }
 }
 
-template <typename T, int LPP>
+template <typename T, int LPP, int V>
 __global__ __launch_bounds__(256) void pn_bwd_kernel(const T* __restrict__ gy, const float* __restrict__ gr,
                                                      const T* __restrict__ y, const float* __restrict__ rn,
                                                      T* __restrict__ gc, long npix, int C, float slope,
@@ -38,23 +48,37 @@ __global__ __launch_bounds__(256) void pn_bwd_kernel(const T* __restrict__ gy, c
     const long pix = gid / LPP;
     const int sub = (int)(gid % LPP);
     const bool ok = pix < npix;
-    float4 g = ok ? lda4(gy + pix * C + sub * 4) : f4zero();
-    if (gy2 && ok) g = f4add(g, lda4(gy2 + pix * C + sub * 4));      // a second contribution to the same gradient, summed here
-    const float4 yy = ok ? lda4(y + pix * C + sub * 4) : f4zero();
+    const long off = pix * C + sub * 4 * V;
+    float4 g[V], g2[V], yy[V];
+    if (ok) {
+        ldav<T, V>(gy + off, g);
+        ldav<T, V>(y + off, yy);
+        if (gy2) ldav<T, V>(gy2 + off, g2);      // a second contribution to the same gradient, summed here
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        if (!ok) { g[i] = f4zero(); yy[i] = f4zero(); }
+        if (gy2 && ok) g[i] = f4add(g[i], g2[i]);
+        d += f4dot(g[i], yy[i]);
+    }
     const float r = ok ? rn[pix] : 1.f;
     const float inv_c = 1.0f / (float)C;
-    const float s = group_sum<LPP>(f4dot(g, yy)) * inv_c;
+    const float s = group_sum<LPP>(d) * inv_c;
     const float inv_r = 1.0f / r;
     const float k = (gr && ok) ? gr[pix] * inv_c : 0.f;
-    float4 o;
-    o.x = ((g.x - yy.x * s) * inv_r + k * yy.x) * lrelu_mask(yy.x, slope);
-    o.y = ((g.y - yy.y * s) * inv_r + k * yy.y) * lrelu_mask(yy.y, slope);
-    o.z = ((g.z - yy.z * s) * inv_r + k * yy.z) * lrelu_mask(yy.z, slope);
-    o.w = ((g.w - yy.w * s) * inv_r + k * yy.w) * lrelu_mask(yy.w, slope);
-    if (ok) sta4(gc + pix * C + sub * 4, o);
+    float4 o[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        o[i].x = ((g[i].x - yy[i].x * s) * inv_r + k * yy[i].x) * lrelu_mask(yy[i].x, slope);
+        o[i].y = ((g[i].y - yy[i].y * s) * inv_r + k * yy[i].y) * lrelu_mask(yy[i].y, slope);
+        o[i].z = ((g[i].z - yy[i].z * s) * inv_r + k * yy[i].z) * lrelu_mask(yy[i].z, slope);
+        o[i].w = ((g[i].w - yy[i].w * s) * inv_r + k * yy[i].w) * lrelu_mask(yy[i].w, slope);
+    }
+    if (ok) stav<T, V>(gc + off, o);
 }
 
-template <typename T, int LPP>
+template <typename T, int LPP, int V>
 __global__ __launch_bounds__(256) void pn_bwdbwd_kernel(const T* __restrict__ h, const T* __restrict__ gy,
                                                         const T* __restrict__ y, const float* __restrict__ rn,
                                                         T* __restrict__ ggy, T* __restrict__ gy_out,
@@ -63,25 +87,38 @@ __global__ __launch_bounds__(256) void pn_bwdbwd_kernel(const T* __restrict__ h,
     const long pix = gid / LPP;
     const int sub = (int)(gid % LPP);
     const bool ok = pix < npix;
-    float4 hp = ok ? lda4(h + pix * C + sub * 4) : f4zero();
-    const float4 g = ok ? lda4(gy + pix * C + sub * 4) : f4zero();
-    const float4 yy = ok ? lda4(y + pix * C + sub * 4) : f4zero();
+    const long off = pix * C + sub * 4 * V;
+    float4 hp[V], g[V], yy[V];
+    if (ok) {
+        ldav<T, V>(h + off, hp);
+        ldav<T, V>(gy + off, g);
+        ldav<T, V>(y + off, yy);
+    }
+    float ds = 0.f, dt = 0.f, du = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        if (!ok) { hp[i] = f4zero(); g[i] = f4zero(); yy[i] = f4zero(); }
+        hp[i].x *= lrelu_mask(yy[i].x, slope); hp[i].y *= lrelu_mask(yy[i].y, slope);
+        hp[i].z *= lrelu_mask(yy[i].z, slope); hp[i].w *= lrelu_mask(yy[i].w, slope);
+        ds += f4dot(g[i], yy[i]); dt += f4dot(hp[i], yy[i]); du += f4dot(hp[i], g[i]);
+    }
     const float r = ok ? rn[pix] : 1.f;
-    hp.x *= lrelu_mask(yy.x, slope); hp.y *= lrelu_mask(yy.y, slope);
-    hp.z *= lrelu_mask(yy.z, slope); hp.w *= lrelu_mask(yy.w, slope);
     const float inv_c = 1.0f / (float)C;
-    const float s = group_sum<LPP>(f4dot(g, yy)) * inv_c;
-    const float t = group_sum<LPP>(f4dot(hp, yy)) * inv_c;
-    const float u = group_sum<LPP>(f4dot(hp, g)) * inv_c;
+    const float s = group_sum<LPP>(ds) * inv_c;
+    const float t = group_sum<LPP>(dt) * inv_c;
+    const float u = group_sum<LPP>(du) * inv_c;
     const float inv_r = 1.0f / r;
     if (ok) {
-        float4 a, bq;
-        a.x = (hp.x - yy.x * t) * inv_r; a.y = (hp.y - yy.y * t) * inv_r;
-        a.z = (hp.z - yy.z * t) * inv_r; a.w = (hp.w - yy.w * t) * inv_r;
-        bq.x = -(s * hp.x + t * g.x) * inv_r; bq.y = -(s * hp.y + t * g.y) * inv_r;
-        bq.z = -(s * hp.z + t * g.z) * inv_r; bq.w = -(s * hp.w + t * g.w) * inv_r;
-        sta4(ggy + pix * C + sub * 4, a);
-        sta4(gy_out + pix * C + sub * 4, bq);
+        float4 a[V], bq[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            a[i].x = (hp[i].x - yy[i].x * t) * inv_r; a[i].y = (hp[i].y - yy[i].y * t) * inv_r;
+            a[i].z = (hp[i].z - yy[i].z * t) * inv_r; a[i].w = (hp[i].w - yy[i].w * t) * inv_r;
+            bq[i].x = -(s * hp[i].x + t * g[i].x) * inv_r; bq[i].y = -(s * hp[i].y + t * g[i].y) * inv_r;
+            bq[i].z = -(s * hp[i].z + t * g[i].z) * inv_r; bq[i].w = -(s * hp[i].w + t * g[i].w) * inv_r;
+        }
+        stav<T, V>(ggy + off, a);
+        stav<T, V>(gy_out + off, bq);
         if (sub == 0) gr_out[pix] = -(float)C * (u - s * t) * inv_r * inv_r;
     }
 }
@@ -92,20 +129,28 @@ bool lpp_ok(int C) {
     return l <= 64 && (l & (l - 1)) == 0;
 }
 
-#define PN_DISPATCH(KERNEL, ...)                                                                                  \
+// lanes per pixel = C / (4 V);  V = 2 (16-byte accesses) for bf16 storage whenever C is a multiple of 8
+#define PN_LAUNCH(KERNEL, VV, ...)                                                                                \
     do {                                                                                                          \
-        const int lpp = C / 4;                                                                                    \
+        const int lpp = C / (4 * VV);                                                                             \
         const dim3 grid(ngan::ceil_div(npix * lpp, 256)), block(256);                                              \
         hipStream_t s_ = (hipStream_t)stream;                                                                     \
         switch (lpp) {                                                                                            \
-            case 1: hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, s_, __VA_ARGS__); break;                        \
-            case 2: hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, s_, __VA_ARGS__); break;                        \
-            case 4: hipLaunchKernelGGL((KERNEL<T, 4>), grid, block, 0, s_, __VA_ARGS__); break;                        \
-            case 8: hipLaunchKernelGGL((KERNEL<T, 8>), grid, block, 0, s_, __VA_ARGS__); break;                        \
-            case 16: hipLaunchKernelGGL((KERNEL<T, 16>), grid, block, 0, s_, __VA_ARGS__); break;                      \
-            case 32: hipLaunchKernelGGL((KERNEL<T, 32>), grid, block, 0, s_, __VA_ARGS__); break;                      \
-            default: hipLaunchKernelGGL((KERNEL<T, 64>), grid, block, 0, s_, __VA_ARGS__); break;                      \
+            case 1: hipLaunchKernelGGL((KERNEL<T, 1, VV>), grid, block, 0, s_, __VA_ARGS__); break;                 \
+            case 2: hipLaunchKernelGGL((KERNEL<T, 2, VV>), grid, block, 0, s_, __VA_ARGS__); break;                 \
+            case 4: hipLaunchKernelGGL((KERNEL<T, 4, VV>), grid, block, 0, s_, __VA_ARGS__); break;                 \
+            case 8: hipLaunchKernelGGL((KERNEL<T, 8, VV>), grid, block, 0, s_, __VA_ARGS__); break;                 \
+            case 16: hipLaunchKernelGGL((KERNEL<T, 16, VV>), grid, block, 0, s_, __VA_ARGS__); break;               \
+            case 32: hipLaunchKernelGGL((KERNEL<T, 32, VV>), grid, block, 0, s_, __VA_ARGS__); break;               \
+            default: hipLaunchKernelGGL((KERNEL<T, 64, VV>), grid, block, 0, s_, __VA_ARGS__); break;               \
         }                                                                                                         \
+    } while (0)
+#define PN_DISPATCH(KERNEL, ...)                                                                                  \
+    do {                                                                                                          \
+        if constexpr (sizeof(T) == 2) {                                                                           \
+            if (C % 8 == 0) { PN_LAUNCH(KERNEL, 2, __VA_ARGS__); break; }                                         \
+        }                                                                                                         \
+        PN_LAUNCH(KERNEL, 1, __VA_ARGS__);                                                                        \
     } while (0)
 
 // T = float: the fp32 contract of include/ngan.h, with csrc/wide.hip behind it for channel counts outside the lane-group kernels'

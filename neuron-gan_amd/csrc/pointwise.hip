@@ -114,24 +114,31 @@ __device__ __forceinline__ float load_img(const float* __restrict__ x, int b, in
 }
 
 // one thread per (pixel, channel quad); blockIdx.y = image row (b*H + y), so no per-item division by W or H
-template <typename T, int POOL>
+// (V float4s per thread: 2 for bf16 storage, i.e. 16-byte stores)
+template <typename T, int POOL, int V>
 __global__ __launch_bounds__(256) void from_image_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, T* __restrict__ y,
                                                              int B, int H, int W, int Ncol, int C) {
-    const unsigned Q = C / 4;
-    const unsigned it = blockIdx.x * 256 + threadIdx.x;        // item inside the row: xx * Q + channel quad
+    const unsigned Q = C / (4 * V);
+    const unsigned it = blockIdx.x * 256 + threadIdx.x;        // item inside the row: xx * Q + channel group
     if (it >= (unsigned)W * Q) return;
     const int xx = (int)(it / Q);
-    const int c0 = (int)(it - (unsigned)xx * Q) * 4;
+    const int c0 = (int)(it - (unsigned)xx * Q) * 4 * V;
     const int row = blockIdx.y;
     const int b = row / H, yy = row - b * H;
-    float4 o = bias ? ld4(bias + c0) : f4zero();
+    float4 o[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = bias ? ld4(bias + c0 + 4 * i) : f4zero();
     for (int k = 0; k < Ncol; ++k) {
         const float v = load_img<POOL>(x, b, yy, xx, k, H, W, Ncol);
-        o.x = fmaf(w[(c0 + 0) * Ncol + k], v, o.x); o.y = fmaf(w[(c0 + 1) * Ncol + k], v, o.y);
-        o.z = fmaf(w[(c0 + 2) * Ncol + k], v, o.z); o.w = fmaf(w[(c0 + 3) * Ncol + k], v, o.w);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = c0 + 4 * i;
+            o[i].x = fmaf(w[(c + 0) * Ncol + k], v, o[i].x); o[i].y = fmaf(w[(c + 1) * Ncol + k], v, o[i].y);
+            o[i].z = fmaf(w[(c + 2) * Ncol + k], v, o[i].z); o[i].w = fmaf(w[(c + 3) * Ncol + k], v, o[i].w);
+        }
     }
-    sta4(y + ((long)row * W + xx) * C + c0, o);
+    stav<T, V>(y + ((long)row * W + xx) * C + c0, o);
 }
 
 template <typename T, int Q, int POOL>
@@ -237,44 +244,78 @@ __global__ __launch_bounds__(256) void to_image_fwd_kernel(const T* __restrict__
 
 // rn != nullptr: x is the output of a LeakyReLU -> PixelNorm with norms rn, and gx receives the gradient w.r.t. that operator's
 // INPUT (its backward is applied to the ToImage input-gradient before the store: one pass instead of two over the activation)
-template <typename T, int Q>
+// Q lanes per pixel, V float4s (4 V channels) per lane: V = 2 for bf16 storage (16-byte accesses), and two pixels per loop trip, so that
+// a wave has 2 KB instead of 512 B of the activation in flight (the bf16 form of the V = 1, one-pixel loop ran at 2.5 TB/s)
+template <typename T, int Q, int V>
 __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restrict__ g, const float* __restrict__ t,
                                                            const T* __restrict__ x, const float* __restrict__ w,
                                                            T* __restrict__ gx, float* __restrict__ partial,
                                                            long npix, int C, int Ncol, const float* __restrict__ rn, float slope) {
     __shared__ float4 red[256];
+    constexpr int U = V;                                  // pixels per loop trip
     const int tid = threadIdx.x, sub = tid % Q;
     const long stride = (long)gridDim.x * (256 / Q);
-    float4 acc[4];
+    float4 acc[4][V];
+    float4 wv[4][V];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = f4zero();
-    float4 wv[4];
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wv[k] = k < Ncol ? ld4(w + k * C + sub * 4) : f4zero();
-    // (the trip count is the same for all Q lanes of a pixel group only if npix is a multiple of 256 / Q per stride step; lanes of
-    // one pixel always iterate together, which is all the group shuffle below needs)
-    for (long pix = (long)blockIdx.x * (256 / Q) + tid / Q; pix < npix; pix += stride) {
-        const float4 xv = lda4(x + pix * C + sub * 4);
-        float4 o = f4zero();
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < Ncol) {
-                const float tv = t[pix * Ncol + k];
-                const float qv = g[pix * Ncol + k] * (1.0f - tv * tv);
-                o = f4fma(wv[k], qv, o);
-                acc[k] = f4fma(xv, qv, acc[k]);
-            }
-        if (rn) {
-            const float sdot = group_sum<Q>(f4dot(o, xv)) * (1.0f / (float)C);
-            o = pn_bwd4_pw(o, xv, sdot, 1.0f / rn[pix], slope);
+        for (int i = 0; i < V; ++i) {
+            acc[k][i] = f4zero();
+            wv[k][i] = k < Ncol ? ld4(w + k * C + (sub * V + i) * 4) : f4zero();
         }
-        sta4(gx + pix * C + sub * 4, o);
+    // (lanes of one pixel always iterate together, which is all the group shuffle below needs)
+    for (long pix0 = (long)blockIdx.x * (256 / Q) + tid / Q; pix0 < npix; pix0 += U * stride) {
+        float4 xv[U][V];
+        float qv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = pix0 + u * stride;
+            if (pix < npix) {
+                ldav<T, V>(x + pix * C + sub * 4 * V, xv[u]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < Ncol) {
+                        const float tv = t[pix * Ncol + k];
+                        qv[u][k] = g[pix * Ncol + k] * (1.0f - tv * tv);
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = pix0 + u * stride;
+            const bool ok = pix < npix;             // (uniform over the Q lanes of a pixel)
+            float4 o[V];
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                o[i] = f4zero();
+                if (!ok) xv[u][i] = f4zero();
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < Ncol && ok) {
+                        o[i] = f4fma(wv[k][i], qv[u][k], o[i]);
+                        acc[k][i] = f4fma(xv[u][i], qv[u][k], acc[k][i]);
+                    }
+                d += f4dot(o[i], xv[u][i]);
+            }
+            if (rn) {
+                const float sdot = group_sum<Q>(d) * (1.0f / (float)C);
+                const float inv_r = ok ? 1.0f / rn[pix] : 0.f;
+#pragma unroll
+                for (int i = 0; i < V; ++i) o[i] = pn_bwd4_pw(o[i], xv[u][i], sdot, inv_r, slope);
+            }
+            if (ok) stav<T, V>(gx + pix * C + sub * 4 * V, o);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (k < Ncol) {
-            float4 s = block_quad_sum<Q>(acc[k], red);
-            if (tid < Q) st4(partial + (long)blockIdx.x * C * Ncol + k * C + tid * 4, s);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float4 s = block_quad_sum<Q>(acc[k][i], red);
+                if (tid < Q) st4(partial + (long)blockIdx.x * C * Ncol + k * C + (tid * V + i) * 4, s);
+            }
         }
 }
 
@@ -705,9 +746,17 @@ static int from_image_fwd_impl(const float* x, const float* w, const float* b, T
     NGAN_REQUIRE((long)B * H * W * (C / 4) < (1L << 31), NGAN_ERR_SHAPE, "from_image_fwd: B*H*W*C/4 must be below 2^31");
     hipStream_t s = (hipStream_t)stream;
     NGAN_REQUIRE((long)B * H < 65536, NGAN_ERR_SHAPE, "from_image_fwd: B*H must be below 65536");
-    const dim3 grid(ceil_div((long)W * (C / 4), 256), B * H);
-    if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<T, 1>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
-    else hipLaunchKernelGGL((from_image_fwd_kernel<T, 0>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    bool wide_access = false;
+    if constexpr (!is_f32<T>()) wide_access = C % 8 == 0;              // bf16 storage: 8 channels (16 bytes) per thread
+    if (wide_access) {
+        const dim3 grid(ceil_div((long)W * (C / 8), 256), B * H);
+        if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<T, 1, 2>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+        else hipLaunchKernelGGL((from_image_fwd_kernel<T, 0, 2>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    } else {
+        const dim3 grid(ceil_div((long)W * (C / 4), 256), B * H);
+        if (pool) hipLaunchKernelGGL((from_image_fwd_kernel<T, 1, 1>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+        else hipLaunchKernelGGL((from_image_fwd_kernel<T, 0, 1>), grid, dim3(256), 0, s, x, w, b, y, B, H, W, Ncol, C);
+    }
     return ngan::launch_status("ngan_from_image_fwd");
 }
 extern "C" int ngan_from_image_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int Ncol,
@@ -827,9 +876,20 @@ static int to_image_bwd_impl(const float* g, const float* t, const T* x, const f
                  npix, C, Ncol);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = stream_blocks(npix, C / 4);
-#define CALL(QV) hipLaunchKernelGGL((to_image_bwd_kernel<T, QV>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope)
-    Q_DISPATCH(CALL)
+    bool wide_access = false;
+    if constexpr (!is_f32<T>()) wide_access = C % 8 == 0;              // bf16 storage: 8 channels (16 bytes) per lane
+    if (wide_access) {
+        switch (C / 8) {
+#define CALL(QV) case QV: hipLaunchKernelGGL((to_image_bwd_kernel<T, QV, 2>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope); break;
+            CALL(1) CALL(2) CALL(4) CALL(8) CALL(16) CALL(32)
 #undef CALL
+            default: NGAN_REQUIRE(false, NGAN_ERR_SHAPE, "to_image_bwd: C=%d unsupported", C);
+        }
+    } else {
+#define CALL(QV) hipLaunchKernelGGL((to_image_bwd_kernel<T, QV, 1>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope)
+        Q_DISPATCH(CALL)
+#undef CALL
+    }
     int st = ngan::launch_status("ngan_to_image_bwd");
     if (st) return st;
     return ngan::reduce_partials_acc(workspace, nblk, C * Ncol, C * Ncol, gw, C * Ncol, nullptr, 1.0f, accumulate ? 1 : 0, s);
