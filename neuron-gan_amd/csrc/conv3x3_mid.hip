@@ -123,50 +123,58 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_mid_kernel(ConvArgs a, int r
     // ---- stage the halo tile, split into bf16 hi / lo.  Branch-free: plain input through a buffer descriptor of the image (an
     // out-of-range offset = conv padding / unused slot reads zeros); resampled input from a clamped address, zeroed afterwards ----
     constexpr int CQ = K / 4, NITEM = NPIX * CQ, NST = (NITEM + NT - 1) / NT;
-    float4 stg[NST];
+    auto to_lds = [&](int e, float4 v) {
+        const int pix = e / CQ, c4 = e % CQ;
+        if (!PREC) {
+            *reinterpret_cast<float4*>(smem + pix * PITCH + c4 * 16) = v;
+            return;
+        }
+        bf16x4 hi, lo;
+        hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+        lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+        lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+        unsigned char* dst = smem + pix * PITCH + (c4 >> 3) * 128 + (c4 & 7) * 8;
+        *reinterpret_cast<bf16x4*>(dst) = hi;
+        *reinterpret_cast<bf16x4*>(dst + 64) = lo;
+    };
+    // Plain input: every item of the thread is requested before the first one is written (NST x 16 B in flight per lane).  Resampled
+    // input has four sources per item; requested all at once they were the kernel's register maximum (K = 128: 14 x 4 x 16 B per lane =
+    // 224 VGPRs + the weight ring: 256 with spills, one workgroup per CU whatever the main loop needs) -- they go in rounds of CH items
     auto stage = [&](auto res_tag) {
         constexpr int RES = decltype(res_tag)::value;
+        constexpr int CH = RES == NGAN_RESAMPLE_NONE ? NST : (NST < 4 ? NST : 4);
         // a.K is the tensor's channel count; it is smaller than the kernel's K only for a 16-channel input padded to 32 (zeros)
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.H * a.W * a.K), 0,
                                                                                  (unsigned)(a.H * a.W * a.K) * 4u, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = tid + i * NT;
-            const int pix = e / CQ, c4 = e % CQ;
-            const int ty = pix / 18, tx = pix - ty * 18;
-            const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-            const bool ok = e < NITEM && c4 * 4 < a.K && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            if (RES == NGAN_RESAMPLE_NONE) {
-                const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.K + c4 * 4) * 4) : OOB;
-                stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
-            } else {
-                const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-                stg[i] = f4select(ok, load_inside<RES>(a.x, b, cy, cx, min(c4 * 4, a.K - 4), a.H, a.W, a.K));
+        for (int i0 = 0; i0 < NST; i0 += CH) {
+            float4 stg[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int e = tid + (i0 + i) * NT;
+                const int pix = e / CQ, c4 = e % CQ;
+                const int ty = pix / 18, tx = pix - ty * 18;
+                const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+                const bool ok = i0 + i < NST && e < NITEM && c4 * 4 < a.K && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                if (RES == NGAN_RESAMPLE_NONE) {
+                    const unsigned off = ok ? (unsigned)(((gy * a.W + gx) * a.K + c4 * 4) * 4) : OOB;
+                    stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+                } else {
+                    const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+                    stg[i] = f4select(ok, load_inside<RES>(a.x, b, cy, cx, min(c4 * 4, a.K - 4), a.H, a.W, a.K));
+                }
             }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int e = tid + (i0 + i) * NT;
+                if (i0 + i < NST && e < NITEM) to_lds(e, stg[i]);
+            }
+            if (RES != NGAN_RESAMPLE_NONE) __builtin_amdgcn_sched_barrier(0);      // keep the rounds apart: the scheduler would hoist every load again
         }
     };
     if (resample == NGAN_RESAMPLE_NONE) stage(std::integral_constant<int, NGAN_RESAMPLE_NONE>());
     else if (resample == NGAN_RESAMPLE_POOL2) stage(std::integral_constant<int, NGAN_RESAMPLE_POOL2>());
     else stage(std::integral_constant<int, NGAN_RESAMPLE_UP2>());
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        const int e = tid + i * NT;
-        if (e < NITEM) {
-            const int pix = e / CQ, c4 = e % CQ;
-            const float4 v = stg[i];
-            if (!PREC) {
-                *reinterpret_cast<float4*>(smem + pix * PITCH + c4 * 16) = v;
-                continue;
-            }
-            bf16x4 hi, lo;
-            hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-            lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-            lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
-            unsigned char* dst = smem + pix * PITCH + (c4 >> 3) * 128 + (c4 & 7) * 8;
-            *reinterpret_cast<bf16x4*>(dst) = hi;
-            *reinterpret_cast<bf16x4*>(dst + 64) = lo;
-        }
-    }
     __syncthreads();
 
     f32x4 acc[PGW][MTW];

@@ -48,6 +48,25 @@ constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }
 // 16 accumulators (one per position of the 4x4 transformed tile) instead of 9 taps; 64 instead of 144 MFMAs per wave and tile.
 // The G^T . G back-transform is linear, so every workgroup applies it to its own partial sum before writing the slab: slab
 // format, slab reduction and bit-reproducibility are those of the direct form.
+// Phase-timer build only (`make phases`: -DNGAN_DIAG -DNGAN_DIAG_PHASES, build/phases/): where a wave's time goes, phase by phase
+// (shader clock, summed over the waves of a launch; read back through ngan_diag_wgrad_phases -- tools/wgrad_phases.py).  0 = waiting at the
+// tile's first barrier (the other waves still computing), 1 = waiting for this tile's global loads, 2 = LDS writes, 3 = second barrier,
+// 4 = issuing the next tile's loads, 5 = operand reads + transforms + MFMAs, 6 = the tail's first barrier (the waves' skew at the end of the
+// loop), 7 = the four cross-wave reduction passes, 8 = row transform (Z = dU G) through LDS, 9 = column transform + slab store, 10 = number of
+// waves sampled (one workgroup in eight reports: the counters' atomics at the end of a wave would otherwise disturb the other waves' tails).
+#ifdef NGAN_DIAG_PHASES
+__device__ unsigned long long wgrad_phase_ctr[11];
+#define PHASE_INIT unsigned long long ph_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter()
+#define PHASE_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] += now_ - last_; last_ = now_; }
+#define PHASE_WAIT_LOADS asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PHASE_FLUSH if (lane == 0 && (blockIdx.x & 7) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&wgrad_phase_ctr[i_], ph_[i_]); atomicAdd(&wgrad_phase_ctr[10], 1ull); }
+#else
+#define PHASE_INIT
+#define PHASE_STAMP(i)
+#define PHASE_WAIT_LOADS
+#define PHASE_FLUSH
+#endif
+
 template <int COT, int CIT, int RES, int TW, int NW, int XF, int WINO = 0>
 __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 || NW == 4 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
     // Winograd form: a wave step covers 16 Winograd tiles -- one row of an 8 x 32 tile, or (TW = 16: images at most 16 pixels wide)
@@ -214,8 +233,12 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
 
     int tile = blockIdx.x;
     if (tile < a.n_tiles) issue(tile);
+    PHASE_INIT;
     while (tile < a.n_tiles) {
         __syncthreads();
+        PHASE_STAMP(0);
+        PHASE_WAIT_LOADS;
+        PHASE_STAMP(1);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             float* d = g_lds + g_l[i];
@@ -262,9 +285,12 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
                     d[0] = xst[i].x; d[PLANE_X] = xst[i].y; d[2 * PLANE_X] = xst[i].z; d[3 * PLANE_X] = xst[i].w;
                 }
         }
+        PHASE_STAMP(2);
         __syncthreads();
+        PHASE_STAMP(3);
         const int tn = tile + gridDim.x;
         if (tn < a.n_tiles) issue(tn);   // next tile's loads are in flight during the MFMAs
+        PHASE_STAMP(4);
         if (WINO) {
             // this wave's tile rows: output rows row0, row0 + 1 = halo rows row0 .. row0 + 3.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] is used
             // without the minus signs of its last row (one negation per element saved); the back-transform flips the sign of every
@@ -343,11 +369,13 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
                 }
             }
         }
+        PHASE_STAMP(5);
         tile = tn;
     }
 
     // ---- sum the WR row-waves of each sub-slice through LDS (fixed order), then write this block's slab ----
     __syncthreads();
+    PHASE_STAMP(6);
     float4* red = reinterpret_cast<float4*>(smem);
     float* slab = a.partial + ((long)blockIdx.x * gridDim.y + slice) * (9 * CO_S * CI_S);
     if (!WINO) {
@@ -388,6 +416,7 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
             }
         }
         __syncthreads();                                     // every thread has read its part of `red`
+        PHASE_STAMP(7);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int item = tid + it * NT, l = item & 63, u = (item >> 6) & 3, o = item >> 8;
@@ -400,6 +429,7 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
             }
         }
         __syncthreads();
+        PHASE_STAMP(8);
         // item (l, i < 3, o): dW[i][j] = sum_u G^T[i][u] Z[u][j]
         for (int item = tid; item < WO * 3 * 64; item += NT) {
             const int l = item & 63, i = (item >> 6) % 3, o = (item >> 6) / 3;
@@ -414,6 +444,8 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
                 op[0] = v.x; op[CI_S] = v.y; op[2 * CI_S] = v.z; op[3 * CI_S] = v.w;
             }
         }
+        PHASE_STAMP(9);
+        PHASE_FLUSH;
         return;
     }
     for (int e = tid; e < WO * 9 * 64; e += NT) {
@@ -973,3 +1005,16 @@ extern "C" int ngan_bf16_conv3x3_wgrad(const ngan_bf16* x, const ngan_bf16* g, f
     return wgrad_entry(reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(g), gw, workspace, B, H, W, Cin, Cout, resample, scale,
                        accumulate, 5, stream);
 }
+
+#ifdef NGAN_DIAG_PHASES
+// phase-timer build only (not declared in include/ngan.h): copies the phase counters of wgrad_f32_kernel out and optionally zeroes them
+extern "C" int ngan_diag_wgrad_phases(unsigned long long* out11, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out11, HIP_SYMBOL(wgrad_phase_ctr), 11 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long z[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wgrad_phase_ctr), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
