@@ -67,6 +67,19 @@ __device__ unsigned long long wgrad_phase_ctr[11];
 #define PHASE_FLUSH
 #endif
 
+// Round 4, measured and NOT kept (profiles/r04_wgrad_phases.txt, r04_micro_mfma_valu.txt, experiments/r04_wgrad_wave_private.diff):
+//  * the lane's ten input columns read once per halo row (two 16-byte + one 8-byte read instead of 16 + 8 per tile pair): 190 VGPRs, two
+//    instead of three workgroups per CU, 34 -> 41 us;
+//  * WAVE-PRIVATE staging for the 16 x 16-slice instance (every wave loads its own two gradient rows and four halo rows into its own LDS
+//    region: no barrier in the tile loop, 67 KB of LDS, 206 VGPRs): the phase timers' 18 % "first barrier" share disappears, the wave's
+//    lifetime falls by 6.6 %, the launch by 0 - 3.5 % in isolation (42.4 -> 40.9 us at 256 x 256 incl. the slab reduction, 157.4 -> 158.7 at
+//    512 x 512) and by nothing inside the iteration (34.0 -> 33.8 us per launch, 7.05 -> 7.07 ms): the time the waves no longer spend at the
+//    barrier they spend queueing for the SIMD's one vector pipe, which the MFMAs (2 048 cycles per wave and tile) and the 176 transform
+//    instructions (3 - 5 cycles each beside an fp32 MFMA, measured) of TWO waves keep ~75 % busy;
+//  * the transforms on register pairs (22 v_pk_* instead of 44 scalar instructions per 16 MFMAs): the compiler's pre-emit peephole splits
+//    packed fp32 instructions in an MFMA's shadow again, and rightly -- beside v_mfma_f32_16x16x4_f32 at two waves per SIMD a packed
+//    instruction costs 5 - 9 cycles of the slot against 3 - 5 for a scalar one (tools/micro/mfma_valu.hip);
+//  * 768 / 1024 instead of 512 workgroups (three per CU): 42.1 -> 43.0 / 46.7 us.
 template <int COT, int CIT, int RES, int TW, int NW, int XF, int WINO = 0>
 __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 || NW == 4 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
     // Winograd form: a wave step covers 16 Winograd tiles -- one row of an 8 x 32 tile, or (TW = 16: images at most 16 pixels wide)

@@ -246,12 +246,16 @@ __global__ __launch_bounds__(256) void to_image_fwd_kernel(const T* __restrict__
 // INPUT (its backward is applied to the ToImage input-gradient before the store: one pass instead of two over the activation)
 // Q lanes per pixel, V float4s (4 V channels) per lane: V = 2 for bf16 storage (16-byte accesses), and two pixels per loop trip, so that
 // a wave has 2 KB instead of 512 B of the activation in flight (the bf16 form of the V = 1, one-pixel loop ran at 2.5 TB/s)
-template <typename T, int Q, int V>
+// NC: the number of image channels when it is known at compile time (1: the grey-scale images of the reference's dataset), 0 = run time
+// (<= 4).  With a run-time count every `k < Ncol` is a branch around a load + wait, and the compiler serialised the small loads of g and t
+// in front of the activation's load: the round-4 templated kernel ran 134 - 140 us where round 3's took 113 (profiles/r04_kernel_stats_f32*).
+template <typename T, int Q, int V, int NC>
 __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restrict__ g, const float* __restrict__ t,
                                                            const T* __restrict__ x, const float* __restrict__ w,
                                                            T* __restrict__ gx, float* __restrict__ partial,
-                                                           long npix, int C, int Ncol, const float* __restrict__ rn, float slope) {
+                                                           long npix, int C, int ncol_rt, const float* __restrict__ rn, float slope) {
     __shared__ float4 red[256];
+    const int Ncol = NC ? NC : ncol_rt;
     constexpr int U = V;                                  // pixels per loop trip
     const int tid = threadIdx.x, sub = tid % Q;
     const long stride = (long)gridDim.x * (256 / Q);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restri
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long pix = pix0 + u * stride;
-            if (pix < npix) {
+            if (U == 1 || pix < npix) {                 // (U = 1: the loop condition already says so -- the fp32 form stays branch-free)
                 ldav<T, V>(x + pix * C + sub * 4 * V, xv[u]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256) void to_image_bwd_kernel(const float* __restri
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long pix = pix0 + u * stride;
-            const bool ok = pix < npix;             // (uniform over the Q lanes of a pixel)
+            const bool ok = U == 1 || pix < npix;   // (uniform over the Q lanes of a pixel)
             float4 o[V];
             float d = 0.f;
 #pragma unroll
@@ -880,13 +884,15 @@ static int to_image_bwd_impl(const float* g, const float* t, const T* x, const f
     if constexpr (!is_f32<T>()) wide_access = C % 8 == 0;              // bf16 storage: 8 channels (16 bytes) per lane
     if (wide_access) {
         switch (C / 8) {
-#define CALL(QV) case QV: hipLaunchKernelGGL((to_image_bwd_kernel<T, QV, 2>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope); break;
+#define CALL(QV) case QV: if (Ncol == 1) hipLaunchKernelGGL((to_image_bwd_kernel<T, QV, 2, 1>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope); \
+                          else hipLaunchKernelGGL((to_image_bwd_kernel<T, QV, 2, 0>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope); break;
             CALL(1) CALL(2) CALL(4) CALL(8) CALL(16) CALL(32)
 #undef CALL
             default: NGAN_REQUIRE(false, NGAN_ERR_SHAPE, "to_image_bwd: C=%d unsupported", C);
         }
     } else {
-#define CALL(QV) hipLaunchKernelGGL((to_image_bwd_kernel<T, QV, 1>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope)
+#define CALL(QV) do { if (Ncol == 1) hipLaunchKernelGGL((to_image_bwd_kernel<T, QV, 1, 1>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope); \
+                      else hipLaunchKernelGGL((to_image_bwd_kernel<T, QV, 1, 0>), dim3(nblk), dim3(256), 0, s, g, t, x, w, gx, workspace, npix, C, Ncol, rn, slope); } while (0)
         Q_DISPATCH(CALL)
 #undef CALL
     }
