@@ -843,7 +843,7 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_wgrad_kernel_name: bad shape");
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
-    if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
+    if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d, false>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
     else if (precision == 5) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d, true>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
     else {
         const bool wino = wgrad_wino_on() && (p.tw == 32 || NGAN_WGRAD_WINO16);
