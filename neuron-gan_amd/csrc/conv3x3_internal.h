@@ -57,6 +57,35 @@ __device__ __forceinline__ TileRun tile_run(int n_tiles) {      // this workgrou
     return r;
 }
 
+// Tile coordinates of a persistent kernel's walk t, t + step, ...: decoded ONCE (the two integer divisions are ~40 scalar instructions each on
+// this ISA, and they used to run twice per tile -- once for the tile being computed, once inside the prefetch of the next one -- in every
+// wave, between the barrier and the issue of the next tile's loads), then advanced by the decomposed step with two carries.
+struct TileCursor { int b, ty, tx; };
+struct TileWalk {
+    int tiles_x, tiles_y, db, dy, dx;
+    __device__ __forceinline__ TileWalk(int tiles_x_, int tiles_y_, int step) : tiles_x(tiles_x_), tiles_y(tiles_y_) {
+        dx = step % tiles_x;
+        const int r = step / tiles_x;
+        dy = r % tiles_y;
+        db = r / tiles_y;
+    }
+    __device__ __forceinline__ TileCursor at(int t) const {
+        TileCursor c;
+        c.tx = t % tiles_x; t /= tiles_x;
+        c.ty = t % tiles_y;
+        c.b = t / tiles_y;
+        return c;
+    }
+    __device__ __forceinline__ TileCursor next(TileCursor c) const {      // the tile `step` further on (dx < tiles_x, dy < tiles_y: one carry each)
+        c.tx += dx;
+        if (c.tx >= tiles_x) { c.tx -= tiles_x; c.ty += 1; }
+        c.ty += dy;
+        if (c.ty >= tiles_y) { c.ty -= tiles_y; c.b += 1; }
+        c.b += db;
+        return c;
+    }
+};
+
 inline int persistent_grid(int n_tiles, int resident) {
     const int per_cu = NGAN_DIAG_INT("NGAN_PERSIST_WG_PER_CU", 0);
     const int cap = per_cu > 0 ? per_cu * 256 : 1 << 30;

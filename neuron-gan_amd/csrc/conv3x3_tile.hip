@@ -126,17 +126,12 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
     if (EPI == EPI_TO_IMAGE) t_voff = WINO ? (unsigned)(((2 * wave + (q >> 1)) * a.W + 2 * p + (q & 1)) * 4)
                                            : (unsigned)(((wave * RPW + (q >> 1)) * a.W + (q & 1) * 16 + p) * 4);
 
-    auto decode = [&](int tt, int& b, int& y0, int& x0) {
-        const int txi = tt % a.tiles_x; tt /= a.tiles_x;
-        const int tyi = tt % a.tiles_y;
-        b = tt / a.tiles_y;
-        y0 = tyi * THc; x0 = txi * 32;
-    };
+    const TileWalk walk(a.tiles_x, a.tiles_y, run.step);
+    TileCursor cur_tile = walk.at(t), next_tile = walk.next(cur_tile);      // tile t and tile t + step
     const unsigned img_bytes = (unsigned)(a.H * a.W * K) * 4u;
     float4 stg[NST];
-    auto issue = [&](int tt) {
-        int b, y0, x0;
-        decode(tt, b, y0, x0);
+    auto issue = [&](const TileCursor& tc) {
+        const int b = tc.b, y0 = tc.ty * THc, x0 = tc.tx * 32;
         const int soff = ((y0 - 1) * a.W + (x0 - 1)) * K * 4;                 // negative on the top row / for the first tile
         const char* base = reinterpret_cast<const char*>(a.x + (long)b * a.H * a.W * K) + soff;
         const unsigned nrec = img_bytes - (unsigned)soff;                     // bytes from `base` to the end of the image
@@ -160,7 +155,7 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
         bvec[mt] = (f32x4){b4.x, b4.y, b4.z, b4.w};
         wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + mt * 16 + q * 4) : f4zero();
     }
-    if (t < t_end) issue(t);
+    if (t < t_end) issue(cur_tile);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) { pin_registers(bvec[mt]); pin_registers(wimg[mt]); }     // (awaited once, here: conv3x3_internal.h)
     const float inv_n = 1.0f / (float)N;
@@ -181,24 +176,23 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
     if (DB && t < t_end) {                         // double-buffered: the first tile is staged here, the second one's loads go out
         stage(tile);
         __syncthreads();
-        if (t + run.step < t_end) issue(t + run.step);
+        if (t + run.step < t_end) issue(next_tile);
     }
     float* const tile0 = tile;
     int cur = 0;
     while (t < t_end) {
-        int b, y0, x0;
-        decode(t, b, y0, x0);
+        const int b = cur_tile.b, y0 = cur_tile.ty * THc, x0 = cur_tile.tx * 32;
         const int tn = t + run.step;
         if (DB) {
             // stg holds tile tn (loaded during the previous tile): into the buffer nobody reads now; then the loads of the tile after it
             tile = tile0 + cur * TILE_ELEMS;
             if (tn < t_end) stage(tile0 + (cur ^ 1) * TILE_ELEMS);
-            if (tn + run.step < t_end) issue(tn + run.step);
+            if (tn + run.step < t_end) issue(walk.next(next_tile));
         } else {
             __syncthreads();   // previous tile's MFMAs have finished reading `tile`
             stage(tile);
             __syncthreads();
-            if (tn < t_end) issue(tn);   // in flight while this tile is computed
+            if (tn < t_end) issue(next_tile);   // in flight while this tile is computed
         }
 
         // ---- per-tile scalars of the epilogue.  The tile's byte offset is ADDED to the per-lane constants (one v_add per access)
@@ -490,6 +484,8 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
             cur ^= 1;
         }
         t = tn;
+        cur_tile = next_tile;
+        next_tile = walk.next(next_tile);
     }
 }
 

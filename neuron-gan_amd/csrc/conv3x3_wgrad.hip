@@ -179,12 +179,8 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
 
     float4 gst[NG], xst[XF ? NXF : (RES == NGAN_RESAMPLE_UP2 ? NXP : NX)];
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    auto issue = [&](int tile) {
-        int t = tile;
-        const int txi = t % a.tiles_x; t /= a.tiles_x;
-        const int tyi = t % a.tiles_y;
-        const int b = t / a.tiles_y;
-        const int y0 = tyi * TH, x0 = txi * TW;
+    auto issue = [&](const TileCursor& tc) {
+        const int b = tc.b, y0 = tc.ty * TH, x0 = tc.tx * TW;
         // g: the tile origin moves the descriptor's base; rows below the image fall outside its records (zeros), columns right
         // of the image are masked per lane (only when W is not a multiple of the tile width)
         {
@@ -245,7 +241,9 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
     const float* xa = x_lds + (cit * 16 + p) * PLANE_X + 4 * q;
 
     int tile = blockIdx.x;
-    if (tile < a.n_tiles) issue(tile);
+    const TileWalk walk(a.tiles_x, a.tiles_y, gridDim.x);       // tiles blockIdx.x, + gridDim.x, ...: decoded once, then advanced (conv3x3_internal.h)
+    TileCursor cur_tile = walk.at(tile), next_tile = walk.next(cur_tile);
+    if (tile < a.n_tiles) issue(cur_tile);
     PHASE_INIT;
     while (tile < a.n_tiles) {
         __syncthreads();
@@ -270,9 +268,7 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
             for (int i = 0; i < NXP; ++i)
                 if (tid + i * NT < NPI) st4(patch + (tid + i * NT) * 4, xst[RES == NGAN_RESAMPLE_UP2 ? i : 0]);
             __syncthreads();
-            int tt = tile;
-            const int txi = tt % a.tiles_x; tt /= a.tiles_x;
-            const int y0 = (tt % a.tiles_y) * TH, x0 = txi * TW;
+            const int y0 = cur_tile.ty * TH, x0 = cur_tile.tx * TW;
 #pragma unroll
             for (int i = 0; i < NX; ++i)
                 if (x_r[i] > -1000) {
@@ -302,7 +298,7 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
         __syncthreads();
         PHASE_STAMP(3);
         const int tn = tile + gridDim.x;
-        if (tn < a.n_tiles) issue(tn);   // next tile's loads are in flight during the MFMAs
+        if (tn < a.n_tiles) issue(next_tile);   // next tile's loads are in flight during the MFMAs
         PHASE_STAMP(4);
         if (WINO) {
             // this wave's tile rows: output rows row0, row0 + 1 = halo rows row0 .. row0 + 3.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] is used
@@ -384,6 +380,8 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
         }
         PHASE_STAMP(5);
         tile = tn;
+        cur_tile = next_tile;
+        next_tile = walk.next(next_tile);
     }
 
     // ---- sum the WR row-waves of each sub-slice through LDS (fixed order), then write this block's slab ----
@@ -549,12 +547,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
     for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 gst[NG], xst[NXL];
-    auto issue = [&](int tile) {
-        int t = tile;
-        const int txi = t % a.tiles_x; t /= a.tiles_x;
-        const int tyi = t % a.tiles_y;
-        const int b = t / a.tiles_y;
-        const int y0 = tyi * TH, x0 = txi * TW;
+    auto issue = [&](const TileCursor& tc) {
+        const int b = tc.b, y0 = tc.ty * TH, x0 = tc.tx * TW;
         // loads through per-image buffer descriptors: 32-bit offsets, and an out-of-range offset (tile edge, conv padding, unused
         // staging slot) reads zeros -- no branch around the load and no zero-filled registers (see conv3x3_persist_kernel)
         constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -629,7 +623,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
     };
 
     int tile = blockIdx.x;
-    if (tile < a.n_tiles) issue(tile);
+    const TileWalk walk(a.tiles_x, a.tiles_y, gridDim.x);
+    TileCursor cur_tile = walk.at(tile), next_tile = walk.next(cur_tile);
+    if (tile < a.n_tiles) issue(cur_tile);
     while (tile < a.n_tiles) {
         __syncthreads();
 #pragma unroll
@@ -639,10 +635,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
             for (int i = 0; i < NXL; ++i)
                 if (tid + i * 256 < NPI) st4(patch + (tid + i * 256) * 4, xst[i]);       // patch is plain [py][px][CI_S]
             __syncthreads();
-            int t = tile;
-            const int txi = t % a.tiles_x; t /= a.tiles_x;
-            const int tyi = t % a.tiles_y;
-            const int y0 = tyi * TH, x0 = txi * TW;
+            const int y0 = cur_tile.ty * TH, x0 = cur_tile.tx * TW;
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 if (x_r[i] <= -1000) continue;
@@ -667,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         }
         __syncthreads();
         const int tn = tile + gridDim.x;
-        if (tn < a.n_tiles) issue(tn);
+        if (tn < a.n_tiles) issue(next_tile);
         const __bf16* gh = g_img + cot * G_PIX * 16 + tr0;
         const __bf16* gl = gh + COT * G_PIX * 16;
         const __bf16* xh = x_img + cit * X_PIX * 16 + tr0;
@@ -691,6 +684,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
             }
         }
         tile = tn;
+        cur_tile = next_tile;
+        next_tile = walk.next(next_tile);
     }
 
     __syncthreads();

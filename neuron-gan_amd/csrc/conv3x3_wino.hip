@@ -138,18 +138,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
     unsigned t_voff = 0;                           // ToImage: lane group q finishes pixel group q
     if (EPI == EPI_TO_IMAGE) t_voff = (unsigned)(((2 * tr + (q >> 1)) * a.W + 2 * p + (q & 1)) * 4);
 
-    auto decode = [&](int tt, int& b, int& y0, int& x0) {
-        const int txi = tt % a.tiles_x; tt /= a.tiles_x;
-        const int tyi = tt % a.tiles_y;
-        b = tt / a.tiles_y;
-        y0 = tyi * ROWS; x0 = txi * 32;
-    };
+    const TileWalk walk(a.tiles_x, a.tiles_y, run.step);
+    TileCursor cur_tile = walk.at(t), next_tile = walk.next(cur_tile);      // tile t and tile t + step
     const int lh = a.H >> 1, lw = a.W >> 1;          // low-res extent (bilinear)
     const unsigned img_bytes = (unsigned)((UP ? lh * lw : a.H * a.W) * K) * 4u;
     float4 stg[NST];
-    auto issue = [&](int tt) {
-        int b, y0, x0;
-        decode(tt, b, y0, x0);
+    auto issue = [&](const TileCursor& tc) {
+        const int b = tc.b, y0 = tc.ty * ROWS, x0 = tc.tx * 32;
         if (UP) {
             // the 6 x 18 low-res patch of the tile, loaded with CLAMPED coordinates: the bilinear taps' edge rule
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * lh * lw * K), 0, img_bytes, 0x00020000);
@@ -189,7 +184,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         bvec[mt] = (f32x4){b4.x, b4.y, b4.z, b4.w};
         wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + cb + mt * 16 + q * 4) : f4zero();
     }
-    if (t < t_end) issue(t);
+    if (t < t_end) issue(cur_tile);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) { pin_registers(bvec[mt]); pin_registers(wimg[mt]); }     // (awaited once, here: conv3x3_internal.h)
     const float inv_n = 1.0f / (float)N;
@@ -208,8 +203,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
     };
 
     while (t < t_end) {
-        int b, y0, x0;
-        decode(t, b, y0, x0);
+        const int b = cur_tile.b, y0 = cur_tile.ty * ROWS, x0 = cur_tile.tx * 32;
         __syncthreads();   // previous tile's MFMAs have finished reading `tile` (and its exchange buffers have been read)
         if (UP) {
 #pragma unroll
@@ -228,7 +222,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         if (NS > 1 && nh) __builtin_amdgcn_s_sleep(NGAN_WINO_STAGGER);   // experiment: offset the two waves that share a SIMD and a tile row
 #endif
         const int tn = t + run.step;
-        if (tn < t_end) issue(tn);   // in flight while this tile is computed
+        if (tn < t_end) issue(next_tile);   // in flight while this tile is computed
 
         // ---- per-tile scalars of the epilogue (the tile's byte offset is ADDED to the per-lane constants, one v_add per access:
         // a buffer store with an SGPR soffset reads its data registers late, conv3x3_tile_kernel) ----
@@ -488,6 +482,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), t_rsrc, nh == 0 ? t_voff + p_soff : OOB, 0, 0);
         }
         t = tn;
+        cur_tile = next_tile;
+        next_tile = walk.next(next_tile);
     }
 }
 
