@@ -55,7 +55,7 @@ void pick_tile(int B, int H, int W, int N, int& pgt, bool& narrow) {
         return;
     }
     const long t64 = narrow ? (long)B * ngan::ceil_div(H, 4) * ngan::ceil_div(W, 16) : (long)B * ngan::ceil_div(H, 2) * ngan::ceil_div(W, 32);
-    pgt = t64 >= 256 ? 4 : 2;
+    pgt = t64 >= NGAN_DIAG_INT("NGAN_BF16_T64", 256) ? 4 : 2;      // (threshold: A/B in the diagnostic build)
 }
 
 }  // namespace

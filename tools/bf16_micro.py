@@ -13,6 +13,7 @@ from __graft_entry__ import load_package  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--graph", type=int, default=1, help="1: time the launches inside a replayed HIP graph (default), 0: an eager loop")
 a = ap.parse_args()
 pkg = load_package()
 C, ops = pkg._C, pkg.ops
@@ -40,6 +41,19 @@ def timeit(run):
     for _ in range(3):
         run()
     torch.cuda.synchronize()
+    if a.graph:          # the launches captured into one HIP graph: kernel-bound timing (an eager loop is bound by ~10 us of Python per call)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(a.iters):
+                run()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / a.iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
