@@ -490,8 +490,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base_lo16, const __bf16*
 // PLAIN = true: bf16 activation storage (precision code 5, include/ngan.h "bf16 activation storage"): x and g ARE bf16 tensors, so there
 // is one plane per operand instead of hi + lo, the staging loads are 8 bytes per 4 channels, and a product group is ONE MFMA.
 // Resampled input (avg-pool / bilinear) is blended in fp32 from the bf16 sources and rounded once, like the forward kernel's staging.
-template <int COT, int CIT, int RES, int TW, bool PLAIN = false>
+// XF (plain input, 8 x 32 tiles, image width a multiple of 32): the staging of wgrad_f32_kernel's XF form -- per-lane byte offsets are
+// tile-invariant constants, the tile moves the descriptors' bases with scalar instructions, padding is done by whole loads (top halo row
+// behind a zero-record descriptor, bottom by the range check, the two halo columns in one extra load).  The generic form computes and
+// range-checks an address per load: 118 vector + 106 scalar instructions per tile and wave in front of 18 MFMAs (round-4 ISA count).
+template <int COT, int CIT, int RES, int TW, bool PLAIN = false, bool XF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
+    static_assert(!XF || (RES == NGAN_RESAMPLE_NONE && TW == 32), "fast staging: plain input, 8 x 32 tiles");
     // tile = 256 pixels: 8 x 32, or 16 x 16 for images at most 16 wide.  One k-step = 32 pixels = one tile row (TW = 32) or two
     // consecutive rows (TW = 16): the second 16-pixel half of a fragment then sits one halo row further instead of 16 pixels.
     constexpr int TH = 256 / TW, HALO_H = TH + 2, HALO_W = TW + 2, G_PIX = TH * TW, X_PIX = HALO_H * HALO_W;
@@ -509,7 +514,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
     constexpr int IMG_BYTES = (G_E + X_E) * 2 + PATCH_BYTES;
     constexpr int SMEM_BYTES = IMG_BYTES > RED_BYTES ? IMG_BYTES : RED_BYTES;
     constexpr int NG = G_PIX * (CO_S / 4) / 256, NXI = X_PIX * (CI_S / 4), NX = (NXI + 255) / 256;
-    constexpr int NPI = NPP * (CI_S / 4), NXL = RES == NGAN_RESAMPLE_UP2 ? (NPI + 255) / 256 : NX;   // global loads per thread for x
+    constexpr int Q = CI_S / 4, QG = CO_S / 4;
+    constexpr int NXINT = HALO_H * 32 * Q / 256, NXF = NXINT + 1, N_HALO = 2 * HALO_H * Q;             // XF: interior loads per thread, + the halo-column load
+    static_assert(!XF || ((HALO_H * 32 * Q) % 256 == 0 && N_HALO <= 256), "fast staging layout");
+    constexpr int NPI = NPP * (CI_S / 4), NXL = XF ? NXF : RES == NGAN_RESAMPLE_UP2 ? (NPI + 255) / 256 : NX;   // global loads per thread for x
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
     __bf16* g_img = reinterpret_cast<__bf16*>(smem_raw);
     __bf16* x_img = g_img + G_E;
@@ -539,6 +547,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         x_r[i] = e < NXI ? pix / HALO_W - 1 : -1000; x_c[i] = pix % HALO_W - 1; x_ch[i] = ci0 + c4 * 4;
         x_l[i] = ((c4 >> 2) * X_PIX + pix) * 16 + (c4 & 3) * 4;
     }
+    // XF: byte offsets from the tile origin (g) / the halo origin (y0 - 1, x0 - 1) (x), bf16 index of the hi part in LDS
+    unsigned gf_off[XF ? NG : 1], xf_off[XF ? NXF : 1];
+    int xf_l[XF ? NXF : 1], xf_bits = 8;          // halo load: 1 = left column, 2 = right column, 4 = top row, 8 = unused lane
+    if constexpr (XF) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int e = tid + i * 256, pix = e / QG, c4 = e % QG;
+            gf_off[i] = (unsigned)((((pix >> 5) * a.W + (pix & 31)) * a.N + co0 + c4 * 4) * ESZ);
+        }
+#pragma unroll
+        for (int i = 0; i < NXINT; ++i) {
+            const int e = tid + i * 256, c4 = e % Q, pix = e / Q, r = pix >> 5, c = (pix & 31) + 1;
+            xf_off[i] = (unsigned)(((r * a.W + c) * a.K + ci0 + c4 * 4) * ESZ);
+            xf_l[i] = ((c4 >> 2) * X_PIX + r * HALO_W + c) * 16 + (c4 & 3) * 4;
+        }
+        const int c4 = tid % Q, r = (tid / Q) % HALO_H, side = tid / (Q * HALO_H), c = side ? 33 : 0;
+        const bool used = tid < N_HALO;
+        xf_off[NXINT] = used ? (unsigned)(((r * a.W + c) * a.K + ci0 + c4 * 4) * ESZ) : 0xFFFFFFF0u;
+        xf_l[NXINT] = ((c4 >> 2) * X_PIX + (used ? r : 0) * HALO_W + c) * 16 + (c4 & 3) * 4;
+        xf_bits = used ? ((side ? 2 : 1) | (r == 0 ? 4 : 0)) : 8;
+    }
     // this lane's transposing-read offsets (bf16 elements) inside one plane: pixel 4kq + qq (second read: + 16), channels 4pp..
     const int tr0 = (4 * kq + qq) * 16 + 4 * pp;
 
@@ -547,6 +576,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
     for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 gst[NG], xst[NXL];
+    uint2 graw[XF && PLAIN ? NG : 1], xraw[XF && PLAIN ? NXF : 1];     // XF on bf16 storage: the tile is COPIED (8 bytes per lane and load), not converted
     auto issue = [&](const TileCursor& tc) {
         const int b = tc.b, y0 = tc.ty * TH, x0 = tc.tx * TW;
         // loads through per-image buffer descriptors: 32-bit offsets, and an out-of-range offset (tile edge, conv padding, unused
@@ -555,6 +585,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         // (byte addresses through char*: with PLAIN the tensors behind a.g / a.x hold 2-byte elements)
         const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(reinterpret_cast<const char*>(a.g) + (long)b * a.H * a.W * a.N * ESZ), 0, (unsigned)(a.H * a.W * a.N) * ESZ, 0x00020000);
+        auto load4b = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned bo) -> float4 {     // 4 consecutive channels at byte offset bo
+            if constexpr (PLAIN) {
+                const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, bo, 0, 0));
+                return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+            } else {
+                return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, bo, 0, 0));
+            }
+        };
+        if constexpr (XF) {
+            const char* gb = reinterpret_cast<const char*>(a.g) + (long)b * a.H * a.W * a.N * ESZ;
+            const char* xb = reinterpret_cast<const char*>(a.x) + (long)b * a.H * a.W * a.K * ESZ;
+            const int gs = (y0 * a.W + x0) * a.N * ESZ;                          // rows below the image lie past the records: zeros
+            const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gb + gs), 0, (unsigned)(a.H * a.W * a.N * ESZ) - (unsigned)gs, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                if constexpr (PLAIN) graw[XF && PLAIN ? i : 0] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(g_rs, gf_off[XF ? i : 0], 0, 0));
+                else gst[i] = load4b(g_rs, gf_off[XF ? i : 0]);
+            }
+            const int xs = ((y0 - 1) * a.W + (x0 - 1)) * a.K * ESZ;              // negative on the top row / for the first tile
+            const unsigned nrec = (unsigned)(a.H * a.W * a.K * ESZ) - (unsigned)xs;
+            const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb + xs), 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t x_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb + xs), 0, 0u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NXINT; ++i) {
+                const bool top = i * 256 + wave * 64 < 32 * Q;                   // a wave's load lies in one halo row; row 0 is above the image when y0 = 0
+                if constexpr (PLAIN) xraw[XF && PLAIN ? i : 0] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64((top && y0 == 0) ? x_none : x_rs, xf_off[XF ? i : 0], 0, 0));
+                else xst[XF ? i : 0] = load4b((top && y0 == 0) ? x_none : x_rs, xf_off[XF ? i : 0]);
+            }
+            const int bad = (x0 == 0 ? 1 : 0) | (x0 + 32 >= a.W ? 2 : 0) | (y0 == 0 ? 4 : 0) | 8;
+            const unsigned hoff = (xf_bits & bad) ? OOB : xf_off[XF ? NXINT : 0];
+            if constexpr (PLAIN) xraw[XF && PLAIN ? NXINT : 0] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(x_rs, hoff, 0, 0));
+            else xst[XF ? NXINT : 0] = load4b(x_rs, hoff);
+            return;
+        }
         auto load4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> float4 {     // 4 consecutive channels at element-offset off
             const unsigned bo = off == OOB ? OOB : off * (unsigned)ESZ;          // out of range: the descriptor's range check returns zeros
             if constexpr (PLAIN) {
@@ -629,7 +693,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
     while (tile < a.n_tiles) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NG; ++i) split_store(g_img, g_l[i], COT * G_PIX * 16, gst[i]);
+        for (int i = 0; i < NG; ++i) {
+            if constexpr (XF && PLAIN) *reinterpret_cast<uint2*>(g_img + g_l[i]) = graw[XF && PLAIN ? i : 0];
+            else split_store(g_img, g_l[i], COT * G_PIX * 16, gst[i]);
+        }
         if (RES == NGAN_RESAMPLE_UP2) {
 #pragma unroll
             for (int i = 0; i < NXL; ++i)
@@ -653,6 +720,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
                 }
                 split_store(x_img, x_l[i], CIT * X_PIX * 16, v);
             }
+        } else if constexpr (XF) {
+#pragma unroll
+            for (int i = 0; i < NXF; ++i)
+                if (i < NXINT || tid < N_HALO) {
+                    if constexpr (PLAIN) *reinterpret_cast<uint2*>(x_img + xf_l[XF ? i : 0]) = xraw[XF && PLAIN ? i : 0];
+                    else split_store(x_img, xf_l[XF ? i : 0], CIT * X_PIX * 16, xst[XF ? i : 0]);
+                }
         } else {
 #pragma unroll
             for (int i = 0; i < NX; ++i)
@@ -780,7 +854,8 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision,
     dim3 grid(p.nwx, p.nslices);
     if (precision == 5) {       // bf16 activation storage: x and g are bf16 tensors (ngan_bf16_conv3x3_wgrad)
         if (p.tw == 32) {
-            if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32, true>), grid, dim3(256), 0, s, a);
+            if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32, true, true>), grid, dim3(256), 0, s, a);
+            else if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32, true>), grid, dim3(256), 0, s, a);
             else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1, 32, true>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2, 32, true>), grid, dim3(256), 0, s, a);
         } else {
@@ -791,7 +866,8 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int res, int precision,
         return ngan::launch_status("ngan_bf16_conv3x3_wgrad");
     }
     if (precision == 1 && p.tw == 32) {
-        if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32>), grid, dim3(256), 0, s, a);
+        if (res == 0 && a.W % 32 == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32, false, true>), grid, dim3(256), 0, s, a);
+        else if (res == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 0, 32>), grid, dim3(256), 0, s, a);
         else if (res == 1) hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 1, 32>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_bf16x3_kernel<COT, CIT, 2, 32>), grid, dim3(256), 0, s, a);
         return ngan::launch_status("ngan_conv3x3_wgrad(bf16x3)");
@@ -838,8 +914,9 @@ extern "C" int ngan_conv3x3_wgrad_kernel_name(int B, int H, int W, int Cin, int 
     NGAN_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, NGAN_ERR_SHAPE,
                  "conv3x3_wgrad_kernel_name: bad shape");
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, precision);
-    if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d, false>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
-    else if (precision == 5) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d, true>", p.co_s / 16, p.ci_s / 16, resample, p.tw);
+    const char* xf = (resample == 0 && p.tw == 32 && W % 32 == 0) ? "true" : "false";
+    if (precision == 1) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d, false, %s>", p.co_s / 16, p.ci_s / 16, resample, p.tw, xf);
+    else if (precision == 5) snprintf(buf, len, "wgrad_bf16x3_kernel<%d, %d, %d, %d, true, %s>", p.co_s / 16, p.ci_s / 16, resample, p.tw, xf);
     else {
         const bool wino = wgrad_wino_on() && (p.tw == 32 || NGAN_WGRAD_WINO16);
         snprintf(buf, len, "wgrad_f32_kernel<%d, %d, %d, %d, %d, %d, %d>", p.co_s / 16, p.ci_s / 16, resample, p.tw,
