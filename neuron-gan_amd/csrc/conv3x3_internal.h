@@ -149,6 +149,25 @@ __device__ __forceinline__ void st_split(float* tile, int idx, float4 v) {
     *reinterpret_cast<bf16x4*>(&tile[KG == 1 ? (idx ^ 8) : (idx + PLANE)]) = lo;
 }
 
+// three-way split (conv3x3_tile_kernel PREC = 3, diagnostic build): hi and mid where the two-way split keeps hi and lo, lo in the same
+// slot of a second plane
+template <int PLANE>
+__device__ __forceinline__ void st_split3(float* tile, int idx, float4 v) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, mid, lo;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (__bf16)x[i];
+        const float r1 = x[i] - (float)hi[i];
+        mid[i] = (__bf16)r1;
+        lo[i] = (__bf16)(r1 - (float)mid[i]);
+    }
+    *reinterpret_cast<bf16x4*>(&tile[idx]) = hi;
+    *reinterpret_cast<bf16x4*>(&tile[idx ^ 8]) = mid;
+    *reinterpret_cast<bf16x4*>(&tile[idx + PLANE]) = lo;
+}
+
 // LDS image of a tile: rows of LP = 40 pixels (>= 34 used), 16 floats per pixel, one plane per 16-channel group.
 // The 16-byte quad c of pixel column X is stored at quad (c ^ 2*((X >> 2) & 1)): with that rotation the 16-lane groups of
 // a ds_read_b128 (lanes = 16 consecutive pixels x 4 quads) touch 16 distinct 16-byte slots of a 256-byte bank row

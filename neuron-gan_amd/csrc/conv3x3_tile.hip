@@ -31,13 +31,17 @@ namespace {
 
 template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
 __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_tile_kernel(ConvArgs a, int n_tiles) {
-    // PREC: 0 exact fp32 (direct), 1 split bf16, 2 exact fp32 by Winograd F(2x2, 3x3) (16 -> 16 only; see the MFMA section)
-    constexpr bool BF = PREC == 1, WINO = PREC == 2;
+    // PREC: 0 exact fp32 (direct), 1 split bf16, 2 exact fp32 by Winograd F(2x2, 3x3) (16 -> 16 only; see the MFMA section),
+    // 3 (diagnostic build only: ngan_diag_conv3x3_bf16x6 below) THREE-way split bf16: x = hi + mid + lo covers fp32's 24 significand bits, six of
+    // the nine cross products per fp32 product (hh, hm, mh, hl, lh, mm; the dropped three are <= 2^-24 relative), fp32 accumulation
+    constexpr bool BF = PREC == 1 || PREC == 3, BF6 = PREC == 3, WINO = PREC == 2;
+    constexpr int NPART = BF6 ? 3 : 2;
     static_assert(!WINO || (MTW == 1 && KG == 1), "the Winograd form is built for the 16 -> 16 layers");
+    static_assert(!BF6 || (MTW == 1 && KG == 1), "the three-way split is an experiment on the 16 -> 16 layers");
     constexpr int THc = persist_tile_h(MTW, KG, 0), PGW = THc / 2, RPW = THc / 4;
     constexpr int HH_ = THc + 2, LP = 40;
     constexpr int NSTEP = KG == 1 ? 5 : 9;
-    constexpr int W_ELEMS = BF ? NSTEP * MTW * 2 * 256 : (WINO ? 16 * 256 : 9 * KG * MTW * 256), PLANE = HH_ * LP * 16, TILE_ELEMS = KG * PLANE;
+    constexpr int W_ELEMS = BF ? NSTEP * MTW * NPART * 256 : (WINO ? 16 * 256 : 9 * KG * MTW * 256), PLANE = HH_ * LP * 16, TILE_ELEMS = (BF6 ? 2 : KG) * PLANE;
     constexpr int LPG = HH_ / 2;                 // interior loads per 16-channel group: HH_ rows x 32 columns x 4 quads / 256 threads
     constexpr int NL = KG * LPG, NST = NL + 1;   // + one load for the two halo columns
     constexpr int N_HALO = KG * 2 * HH_ * 4;     // its active lanes: (group, side, row, quad)
@@ -164,12 +168,14 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
     auto stage = [&](float* buf) {                 // the loaded tile (stg) -> LDS image
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            if (BF) st_split<KG, PLANE>(buf, s_lds[i], stg[i]);
+            if (BF6) st_split3<PLANE>(buf, s_lds[i], stg[i]);
+            else if (BF) st_split<KG, PLANE>(buf, s_lds[i], stg[i]);
             else st4(&buf[s_lds[i]], stg[i]);
         }
         pin_registers(stg[NL]);     // every wave awaits the halo load here (the waves that store nothing would carry it, un-awaited, into the next issue)
         if (tid < N_HALO) {
-            if (BF) st_split<KG, PLANE>(buf, s_lds[NL], stg[NL]);
+            if (BF6) st_split3<PLANE>(buf, s_lds[NL], stg[NL]);
+            else if (BF) st_split<KG, PLANE>(buf, s_lds[NL], stg[NL]);
             else st4(&buf[s_lds[NL]], stg[NL]);
         }
     };
@@ -283,6 +289,36 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
             for (int ar = 0; ar < 2; ++ar) {
                 acc[ar * 2 + 0][0] = unpk2(ta[ar][0] + ta[ar][1] + ta[ar][2]);
                 acc[ar * 2 + 1][0] = unpk2(psub(psub(ta[ar][1], ta[ar][2], m1), ta[ar][3], m1));
+            }
+        } else if (BF6) {
+            // weights [step][part hi / mid / lo][lane][8]; tile: hi and mid share the pixel's 64-byte slot (the two-way split's layout), lo
+            // is the same slot of a second plane.  Smallest products first.
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                bf16x8 xh[PGW], xm[PGW], xl[PGW];
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) {
+                    const int row = wave * RPW + (pg >> 1);
+                    const int base = (row * LP + (pg & 1) * 16) * 16 + rs[st];
+                    xh[pg] = *reinterpret_cast<const bf16x8*>(&tile[base]);
+                    xm[pg] = *reinterpret_cast<const bf16x8*>(&tile[base ^ 8]);
+                    xl[pg] = *reinterpret_cast<const bf16x8*>(&tile[base + PLANE]);
+                }
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wl[(st * 3 + 0) * 256 + lane * 4]);
+                const bf16x8 wm = *reinterpret_cast<const bf16x8*>(&wl[(st * 3 + 1) * 256 + lane * 4]);
+                const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(&wl[(st * 3 + 2) * 256 + lane * 4]);
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) acc[pg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh[pg], acc[pg][0], 0, 0, 0);
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) acc[pg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[pg], acc[pg][0], 0, 0, 0);
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) acc[pg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[pg], acc[pg][0], 0, 0, 0);
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) acc[pg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[pg], acc[pg][0], 0, 0, 0);
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) acc[pg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[pg], acc[pg][0], 0, 0, 0);
+#pragma unroll
+                for (int pg = 0; pg < PGW; ++pg) acc[pg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[pg], acc[pg][0], 0, 0, 0);
             }
         } else if (BF) {
 #pragma unroll
@@ -529,3 +565,30 @@ int ngan::conv3x3_tile_launch(const ConvArgs& a, int mtw, int kg, int epilogue, 
     if (mtw == 1) return kg == 1 ? dispatch_tile_prec<1, 1>(a, epilogue, out_mode, tprec, s) : dispatch_tile_prec<1, 2>(a, epilogue, out_mode, tprec, s);
     return kg == 1 ? dispatch_tile_prec<2, 1>(a, epilogue, out_mode, tprec, s) : dispatch_tile_prec<2, 2>(a, epilogue, out_mode, tprec, s);
 }
+
+#ifdef NGAN_DIAG
+// Diagnostic build only (not in include/ngan.h; tools/bf16x6_probe.py): the three-way split-bf16 form of the 16 -> 16 layer on plain input,
+// whole 32-pixel tiles -- the experiment behind the round-2 review's ruling on a "bf16x6" mode.  Packs w (OIHW fp32, 16 x 16 x 3 x 3) * scale
+// into `packed` (5 steps x 3 parts x 512 bf16 = 15 KB) and runs conv3x3_tile_kernel<1, 1, epilogue, 0, 3>; epilogue 0 or 1.
+namespace {
+__global__ void pack_weights_bf16x6_kernel(const float* __restrict__ w, __bf16* __restrict__ packed, float scale) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;                 // [step 5][part 3][lane 64][8]
+    if (idx >= 5 * 3 * 512) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, part = (idx >> 9) % 3, step = idx / (3 * 512);
+    const int n = lane & 15, kk = 8 * (lane >> 4) + j, tap = 2 * step + (kk >> 4), k = kk & 15;
+    float v = tap < 9 ? w[((long)n * 16 + k) * 9 + tap] * scale : 0.f;
+    const __bf16 hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    packed[idx] = part == 0 ? hi : part == 1 ? mid : (__bf16)(r1 - (float)mid);
+}
+}  // namespace
+extern "C" int ngan_diag_conv3x3_bf16x6(const float* x, const float* w, const float* bias, float* y, float* rnorm, float* packed,
+                                        int B, int H, int W, float scale, int epilogue, float slope, float eps, void* stream) {
+    if (!x || !w || !y || !packed || B <= 0 || H <= 0 || W <= 0 || W % 32 || (epilogue != 0 && epilogue != 1) || (epilogue == 1 && !rnorm)) return NGAN_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pack_weights_bf16x6_kernel, dim3(30), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(packed), scale);
+    ConvArgs a{x, packed, bias, y, rnorm, B, H, W, 16, 16, 0, 0, slope, eps, nullptr, nullptr, nullptr};
+    return epilogue ? launch_tile<1, 1, 1, 0, 3>(a, s) : launch_tile<1, 1, 0, 0, 3>(a, s);
+}
+#endif

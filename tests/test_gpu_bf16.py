@@ -190,7 +190,8 @@ def test_bf16_conv_to_image_epilogue(bf16_mode):
 
 
 WGRAD = [(2, 12, 20, 16, 16, 0), (1, 16, 16, 32, 64, 0), (3, 8, 8, 128, 128, 0), (4, 128, 256, 16, 16, 0), (4, 64, 128, 32, 32, 0),
-         (2, 8, 8, 16, 32, 1), (4, 64, 64, 32, 32, 1), (2, 16, 16, 64, 32, 2), (2, 128, 128, 16, 16, 2), (1, 4, 4, 64, 64, 0)]
+         (2, 8, 8, 16, 32, 1), (4, 64, 64, 32, 32, 1), (2, 16, 16, 64, 32, 2), (2, 128, 128, 16, 16, 2), (1, 4, 4, 64, 64, 0),
+         (2, 20, 64, 16, 32, 0), (1, 8, 32, 32, 16, 0), (3, 36, 96, 16, 16, 0)]      # whole 32-pixel tiles (copied staging): ragged height, a single tile, three columns
 
 
 @pytest.mark.parametrize("case", WGRAD)
