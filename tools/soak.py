@@ -1,7 +1,7 @@
 """Soak run of the step driver at the headline shape: N graph-replayed iterations on changing reals, then the same number of eager
 ones; prints ms per iteration per block of 250, the losses at the block ends, allocated device memory and the parameter norms, and
 fails if anything is not finite, memory grows after the first block or a block is more than 5 % slower than the first.
-    python tools/soak.py [--iters 2000] [--res 512] [--batch 16]          (on the GPU box)"""
+    python tools/soak.py [--iters 2000] [--res 512] [--batch 16] [--precision f32|bf16x3|bf16]          (on the GPU box)"""
 import argparse, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +12,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=2000)
 ap.add_argument("--res", type=int, default=512)
 ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"])
 args = ap.parse_args()
 pkg = load_package()
+pkg.ops.set_conv_precision(args.precision)
 dev = torch.device("cuda", 0)
 torch.manual_seed(1)
 G, D = bench.build_nets(pkg, args.res, 1.0, dev)
