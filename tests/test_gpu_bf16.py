@@ -458,3 +458,52 @@ def test_bf16_full_width_configs(bf16_mode, name):
     worst_d = {k: abs(float(np.abs(g.astype(np.float64)).sum()) - fix["cs/Dgrad/" + k][1]) / fix["cs/Dgrad/" + k][1] for k, g in dgrads.items()}
     big = {k: v for k, v in worst_d.items() if fix["cs/Dgrad/" + k][1] > 1e-6}       # (the head bias: a cancelling sum, see test_gpu_models)
     assert max(big.values()) < FULL_TOL_GRAD, big
+
+
+def test_bf16_step_driver_replay_equals_eager(ngan):
+    """The whole step driver in the bf16 mode: a captured HIP graph replayed three times leaves bit-identical parameters to three eager
+    iterations on the same draws (the mode is as reproducible as fp32: fixed-order reductions, no atomics); parameters and Adam state stay
+    fp32; the first iteration's loss statistics (same initial weights, same draws) are the fp32 mode's within the mode's tolerance.
+    (Parameters after several Adam steps are NOT compared across the modes: Adam's first steps move every weight by ~lr times the SIGN of
+    its gradient, and the sign of a near-zero gradient is arbitrary in any arithmetic -- tools/step2_sensitivity.py.)"""
+    def make():
+        torch.manual_seed(5)
+        G = ngan.models.Generator_PG([32, 16, 16], image_size_init=8, latent_dim=32)
+        D = ngan.models.Discriminator_PG([16, 16, 32], image_size_init=8)
+        G.set_resolution(32, 1.0)
+        D.set_resolution(32, 1.0)
+        return ngan.train.PGGANTrainer(G.to(DEV), D.to(DEV), learning_rate=1e-3)
+    gen = torch.Generator().manual_seed(9)
+    def draw(b=8):
+        z = [torch.randn(b, 32, generator=gen) for _ in range(3)]
+        z = [(v / v.norm(dim=1, keepdim=True)).to(DEV) for v in z]
+        return dict(real=(torch.rand(b, 1, 32, 32, generator=gen) * 2 - 1).to(DEV), z_d=z[0], z_gp=z[1],
+                    eps=torch.rand(b, 1, 1, 1, generator=gen).to(DEV), z_g=z[2])
+    seq = [draw() for _ in range(3)]
+    ngan.ops.set_conv_precision("f32")
+    s0 = seq[0]
+    ref_stats = {k: float(v) for k, v in make().train_iteration(s0["real"], s0["z_d"], s0["z_gp"], s0["eps"], s0["z_g"]).items()}
+    try:
+        ngan.ops.set_conv_precision("bf16")
+        assert ngan.ops.act_dtype() == BF
+        eager, tr = make(), make()
+        static = {k: seq[0][k].clone() for k in ("z_d", "z_gp", "eps", "z_g")}
+        tr.capture(seq[0]["real"], draws=static)
+        first = None
+        for s in seq:
+            st = eager.train_iteration(s["real"], s["z_d"], s["z_gp"], s["eps"], s["z_g"])
+            first = first or {k: float(v) for k, v in st.items()}
+            for k, v in static.items():
+                v.copy_(s[k])
+            tr.replay(s["real"])
+        torch.cuda.synchronize()
+        for name, p, pe in zip(tr.flat_g.names + tr.flat_d.names, tr.flat_g.params + tr.flat_d.params, eager.flat_g.params + eager.flat_d.params):
+            assert p.dtype == torch.float32 and bool(torch.isfinite(p).all())
+            assert torch.equal(p, pe), f"{name}: replay differs from eager by {float((p - pe).abs().max())}"
+        for flat in (tr.flat_g, tr.flat_d):
+            assert flat.exp_avg.dtype == torch.float32 and flat.exp_avg_sq.dtype == torch.float32
+        scale = max(1.0, max(abs(v) for v in ref_stats.values()))
+        for k, v in ref_stats.items():
+            assert abs(first[k] - v) <= 5e-2 * scale, f"{k}: {first[k]} in the bf16 mode, {v} in fp32"
+    finally:
+        ngan.ops.set_conv_precision("f32")
