@@ -429,7 +429,9 @@ int launch_bf16(ConvArgsB a, hipStream_t s) {
 }
 
 // N = 16 / 32: pixel split, PGT = 16 / 8 / 4 (8- / 4- / 2-row tiles of 32 columns) and the narrow 4 x 16 tile;
-// N = 64 / 128: output-tile split, PGT = 4 / 2, wide or narrow
+// N = 64 / 128: output-tile split, PGT = 4 / 2, wide or narrow.  (PGT = 8 -- 128 pixels per workgroup, half the L2 weight traffic of a launch
+// with >= 256 such tiles -- was built and measured on BASELINE.json's C2, whose 128 -> 128 layers see 128 images of 16 x 16: iteration
+// 2.39 -> 2.47 ms.  Fewer, longer MFMA chains cost more than the weight stream they save; not kept.)
 template <int K, int N>
 int dispatch_tile(const ConvArgsB& a, int pgt, bool narrow, hipStream_t s) {
     if constexpr (N <= 32) {

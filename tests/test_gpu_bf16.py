@@ -79,6 +79,7 @@ CONV = [
     (6, 64, 128, 32, 64, 0, False), (2, 200, 328, 16, 16, 0, False),                                                                        # 4-row tiles; ragged
     (2, 8, 8, 16, 16, 1, False), (1, 16, 16, 32, 32, 1, True), (3, 10, 20, 64, 32, 1, False), (4, 128, 128, 16, 32, 1, False),              # avg-pool on load
     (2, 8, 8, 32, 16, 2, False), (1, 32, 32, 16, 16, 2, True), (2, 12, 20, 128, 64, 2, True), (4, 128, 256, 32, 16, 2, False),              # bilinear x2 on load
+    (128, 16, 16, 128, 128, 0, True), (16, 64, 64, 32, 64, 0, False), (130, 16, 12, 64, 128, 1, False), (16, 64, 64, 128, 64, 2, True),      # many-channel layers at BASELINE.json C2's sizes (64-pixel tiles of the output-tile split, >= 256 of them)
 ]
 
 
@@ -124,6 +125,7 @@ DGRAD = [
     (2, 12, 20, 16, 16, 0), (1, 16, 16, 32, 64, 0), (4, 128, 256, 16, 16, 0), (4, 128, 256, 32, 16, 0), (1, 8, 8, 128, 128, 0),
     (2, 8, 8, 16, 16, 1), (4, 64, 128, 32, 32, 1), (2, 12, 12, 64, 32, 1),            # pool-adjoint store
     (2, 8, 8, 32, 16, 2), (2, 64, 64, 16, 32, 2),                                     # bilinear adjoint as a second launch
+    (128, 16, 16, 128, 128, 0), (16, 64, 64, 64, 64, 0), (64, 16, 16, 128, 64, 1),    # the same for the input gradient
 ]
 
 
