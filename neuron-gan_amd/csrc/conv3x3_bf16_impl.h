@@ -53,11 +53,13 @@ __device__ __forceinline__ void st4bf(__amdgpu_buffer_rsrc_t rs, unsigned off, f
 // requested before tile t's MFMAs, weights fetched once).  Inside a tile loop the compiler hoists every tile-invariant index -- staging
 // slots, LDS addresses, tap offsets -- into loop-carried registers: 133 instead of 61 for 16 -> 16 (three workgroups per CU instead of
 // eight); capping the registers (launch bounds, lane coordinates behind an opaque barrier) made it spill 44 - 125 registers to scratch
-// instead of recomputing, and the 16 -> 16 forward went from 63 to 152 us.  The one-tile-per-workgroup form below stays: its remedy for
-// "bytes in flight per CU" is occupancy (64 registers, 14 KB of LDS: eight workgroups per CU).
+// instead of recomputing, and the 16 -> 16 forward went from 63 to 152 us.  The one-tile-per-workgroup form below stays: what hides its
+// staging and epilogue latency is occupancy (64 registers, 14 KB of LDS: eight workgroups per CU).
 template <int K, int N, int PGT, bool NS, bool NARROW>
-// (the 16 -> 16 instances fit 64 registers: eight workgroups per CU instead of four -- the kernel is bound by memory round trips per
-// resident workgroup, not by issue: 303 VALU + 20 MFMA instructions per wave and tile, 6 % VALU-busy, PMC profiles/r04_pmc_bf16_1616.txt)
+// (the 16 -> 16 instances fit 64 registers: eight workgroups per CU instead of four.  303 VALU + 190 SALU + 20 MFMA instructions per wave and
+// tile: 47 % of every SIMD's cycles go into vector-instruction issue and some instruction is active 91 % of the time -- the kernel is bound
+// by the instructions of its staging and epilogue, and the extra waves give the issue logic something to pick from while others wait;
+// PMC record and its corrected reading: profiles/r04_pmc_bf16_1616.txt)
 __global__ __launch_bounds__(256, (!NS && K == 16 && N == 16) ? 8 : 1) void conv3x3_bf16_kernel(ConvArgsB a) {
     constexpr int P = K / 8, NT = N / 16, KS = K >= 32 ? K / 32 : 1, S = K == 16 ? 5 : 9 * KS;
     constexpr int TW = NARROW ? 16 : 32, GPR = TW / 16, TH = PGT / GPR, HH = TH + 2, HW = TW + 2, NPIX = HH * HW;
