@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, fixture, q):
+def _worker(rank, world, port, fixture, q, precision="f32"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,6 +32,7 @@ def _worker(rank, world, port, fixture, q):
         from conftest import load_golden
         import test_gpu_models as T
         ngan = load_package()
+        ngan.ops.set_conv_precision(precision)       # bf16: the stem factor that is all-gathered (the gradient w.r.t. the stem's output) is a bf16 tensor
         dev = torch.device("cuda:0")
         fix = load_golden(fixture)
         own = [dist.new_group([r]) for r in range(world)][rank]          # a one-rank group: the single-process reference
@@ -75,12 +76,15 @@ def _worker(rank, world, port, fixture, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
 @pytest.mark.parametrize("fixture", ["small_res16_fade_warm"])
-def test_two_ranks_on_one_gpu_match_the_whole_batch(fixture):
+def test_two_ranks_on_one_gpu_match_the_whole_batch(fixture, precision):
+    """(bf16: every activation is rounded per element whatever the batch split, so two half batches still sum to the whole batch's gradient
+    to fp32 summation order -- the same 2e-4)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, fixture, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, fixture, q, precision)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
