@@ -428,6 +428,17 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
                 if (q == pg) timg = d;          // all four q-lanes hold pixel group pg's sum; lane group q keeps the one it will finish
             }
             if (PNB) {
+#ifdef NGAN_DIAG
+                // Timing experiment (tools/gp_fusion_probe.py, diagnostic build only): what a create_graph pass would need from a fused
+                // input-gradient + PixelNorm-backward kernel -- the gradient BEFORE the PixelNorm backward as a second output (aux_out)
+                if (OUTMODE == 0 && a.aout) {
+                    const __amdgpu_buffer_rsrc_t pre_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.aout + img * N, 0, out_bytes, 0x00020000);
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(lo[mt].x, lo[mt].y, hi[mt].x, hi[mt].y)), pre_rsrc,
+                                                               e_voff[pg] + y_soff + mt * 64, 0, 0);
+                }
+#endif
                 // backward of the LeakyReLU -> PixelNorm that produced this layer's input, applied to the gradient just computed
                 float s = 0.f;
 #pragma unroll
