@@ -52,8 +52,9 @@ constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }
 // (shader clock, summed over the waves of a launch; read back through ngan_diag_wgrad_phases -- tools/wgrad_phases.py).  0 = waiting at the
 // tile's first barrier (the other waves still computing), 1 = waiting for this tile's global loads, 2 = LDS writes, 3 = second barrier,
 // 4 = issuing the next tile's loads, 5 = operand reads + transforms + MFMAs, 6 = the tail's first barrier (the waves' skew at the end of the
-// loop), 7 = the four cross-wave reduction passes, 8 = row transform (Z = dU G) through LDS, 9 = column transform + slab store, 10 = number of
-// waves sampled (one workgroup in eight reports: the counters' atomics at the end of a wave would otherwise disturb the other waves' tails).
+// loop), 7 = the wave's own back-transform + its nine taps written to LDS + barrier (first output group), 8 = fixed-order sum over the row-group
+// waves + slab store (and the further output groups' rounds), 9 = unused, 10 = number of waves sampled (one workgroup in eight reports: with
+// every wave reporting, the atomics of the early finishers stood in the way of the others' tails and tripled the tail's apparent cost).
 #ifdef NGAN_DIAG_PHASES
 __device__ unsigned long long wgrad_phase_ctr[11];
 #define PHASE_INIT unsigned long long ph_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter()
@@ -103,8 +104,7 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
     constexpr int WQ = (COT / CW) * CIT;                         // wave groups over (output group sets, input groups)
     constexpr int WRW = NW / WQ, RPWW = TH / WRW;                // Winograd: row groups, rows per wave
     static_assert(!WINO || (NW % WQ == 0 && TH % WRW == 0 && RPWW % WSTEP_ROWS == 0), "Winograd wave split");
-    // the 16 positions cross the waves in four passes of 4 (virtual wave = (row group, sub-slice)); the back-transform needs 12 per item
-    constexpr int RED_WINO = (WRW * WO * 4 > WO * 12 ? WRW * WO * 4 : WO * 12) * 64 * 4;
+    constexpr int RED_WINO = NW * 9 * 64 * 4;                    // every wave's 9 back-transformed taps of one output group
     constexpr int RED_ELEMS = WINO ? RED_WINO : NW * 9 * 64 * 4;
     // bilinear input: the low-resolution source patch of the halo tile is loaded once (fp32, [py][px][CI_S]) and expanded LDS -> LDS,
     // as in wgrad_bf16x3_kernel: 2 global loads per thread instead of 24, and the tap / weight arithmetic is tile-invariant
@@ -396,65 +396,50 @@ __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT
         __syncthreads();
     }
     if (WINO) {
-        // item (l, u, o): row u of the summed 4x4 position tile of lane l of sub-slice o = cot * CIT + cit (its WRW row-group waves in fixed
-        // order), multiplied by G from the right:  Z[u][j] = sum_v s_v dU[u][v] G[v][j],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
-        // s = (1, 1, 1, -1) (MFMA section).  The positions cross the waves in four passes, one row u of the position tile each.
-        constexpr int ITEMS = WO * 4 * 64, NIT = (ITEMS + NT - 1) / NT;
-        float4 du[NIT][4];
+        // The back-transform  dW = G^T [ s . dU ] G  (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; s = -1 where u = 3 xor v = 3, MFMA section) is linear
+        // and lane-local -- a lane holds all 16 positions of its (cout quad, cin) entries -- so every wave applies it to its OWN partial sums
+        // first (once per launch: ~35 float4 operations per output group) and the waves then exchange 9 taps instead of 16 positions, in ONE
+        // round per output group: two barriers per group instead of eleven in all.  (Round 4: the phase timer showed the old tail -- four
+        // position passes, row transform and column transform each through LDS -- at 30 % of a wave's life on the 64 -> 64 layers, two
+        // tiles per workgroup.)  The summation order changes (transform, then the fixed-order sum over the row-group waves), the bits of a
+        // run stay reproducible.
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            if (pass) __syncthreads();
-#pragma unroll
-            for (int c = 0; c < CW; ++c)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const f32x4 a4 = accw[WINO ? c : 0][pass * 4 + v];
-                    red[((wrw * WO + (cot0w + c) * CIT + citw) * 4 + v) * 64 + lane] = make_float4(a4[0], a4[1], a4[2], a4[3]);
-                }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int item = tid + it * NT, l = item & 63, u = (item >> 6) & 3, o = item >> 8;
-                if (item < ITEMS && u == pass) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        float4 sum = red[((0 * WO + o) * 4 + v) * 64 + l];
-#pragma unroll
-                        for (int w = 1; w < WRW; ++w) sum = f4add(sum, red[((w * WO + o) * 4 + v) * 64 + l]);
-                        du[it][v] = sum;
-                    }
-                }
-            }
-        }
-        __syncthreads();                                     // every thread has read its part of `red`
-        PHASE_STAMP(7);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int item = tid + it * NT, l = item & 63, u = (item >> 6) & 3, o = item >> 8;
-            if (item < ITEMS) {
-                const float su = u == 3 ? -1.f : 1.f;
-                const float4 h12p = f4scale(f4add(du[it][1], du[it][2]), 0.5f), h12m = f4scale(f4add(du[it][1], f4scale(du[it][2], -1.f)), 0.5f);
-                red[((o * 4 + u) * 3 + 0) * 64 + l] = f4scale(f4add(du[it][0], h12p), su);
-                red[((o * 4 + u) * 3 + 1) * 64 + l] = f4scale(h12m, su);
-                red[((o * 4 + u) * 3 + 2) * 64 + l] = f4scale(f4add(h12p, f4scale(du[it][3], -1.f)), su);
-            }
-        }
-        __syncthreads();
-        PHASE_STAMP(8);
-        // item (l, i < 3, o): dW[i][j] = sum_u G^T[i][u] Z[u][j]
-        for (int item = tid; item < WO * 3 * 64; item += NT) {
-            const int l = item & 63, i = (item >> 6) % 3, o = (item >> 6) / 3;
+        for (int c = 0; c < CW; ++c) {
+            if (c) __syncthreads();                              // the previous group's readers are done with `red`
+            // one column j of the 3 x 3 result at a time (Z[.][j] needs the whole row of positions, dW[.][j] the four Z[.][j]): seven live
+            // float4s beside the accumulators, written to LDS as they are finished -- all nine at once cost 45 spilled registers in the
+            // dominant instance
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float4 z_0 = red[((o * 4 + 0) * 3 + j) * 64 + l], z_1 = red[((o * 4 + 1) * 3 + j) * 64 + l];
-                const float4 z_2 = red[((o * 4 + 2) * 3 + j) * 64 + l], z_3 = red[((o * 4 + 3) * 3 + j) * 64 + l];
-                const float4 p12 = f4scale(f4add(z_1, z_2), 0.5f), m12 = f4scale(f4add(z_1, f4scale(z_2, -1.f)), 0.5f);
-                const float4 v = i == 0 ? f4add(z_0, p12) : i == 1 ? m12 : f4add(p12, z_3);
-                const int ci_l = (o % CIT) * 16 + (l & 15), co_l = (o / CIT) * 16 + 4 * (l >> 4);
-                float* op = slab + ((long)(i * 3 + j) * CO_S + co_l) * CI_S + ci_l;
+                f32x4 Zj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 d1 = accw[WINO ? c : 0][u * 4 + 1], d2 = accw[WINO ? c : 0][u * 4 + 2];
+                    const float su = u == 3 ? -1.f : 1.f;
+                    Zj[u] = j == 0 ? (accw[WINO ? c : 0][u * 4 + 0] + (d1 + d2) * 0.5f) * su
+                          : j == 1 ? ((d1 - d2) * 0.5f) * su
+                                   : ((d1 + d2) * 0.5f - accw[WINO ? c : 0][u * 4 + 3]) * su;
+                }
+                const f32x4 p12 = (Zj[1] + Zj[2]) * 0.5f, m12 = (Zj[1] - Zj[2]) * 0.5f;
+                const f32x4 w0 = Zj[0] + p12, w2 = p12 + Zj[3];
+                red[(wave * 9 + 0 * 3 + j) * 64 + lane] = make_float4(w0[0], w0[1], w0[2], w0[3]);      // wave = wrw * WQ + wqw
+                red[(wave * 9 + 1 * 3 + j) * 64 + lane] = make_float4(m12[0], m12[1], m12[2], m12[3]);
+                red[(wave * 9 + 2 * 3 + j) * 64 + lane] = make_float4(w2[0], w2[1], w2[2], w2[3]);
+            }
+            __syncthreads();
+            if (c == 0) PHASE_STAMP(7);
+            // item (l, tap t, oi): wave group oi = (output group set, input group) of this pass, summed over its WRW row-group waves in fixed order
+            for (int item = tid; item < WQ * 9 * 64; item += NT) {
+                const int l = item & 63, t = (item >> 6) % 9, oi = (item >> 6) / 9;
+                float4 v = red[(oi * 9 + t) * 64 + l];
+#pragma unroll
+                for (int w = 1; w < WRW; ++w) v = f4add(v, red[((w * WQ + oi) * 9 + t) * 64 + l]);
+                const int ci_l = (oi % CIT) * 16 + (l & 15), co_l = ((oi / CIT) * CW + c) * 16 + 4 * (l >> 4);
+                float* op = slab + ((long)t * CO_S + co_l) * CI_S + ci_l;
                 op[0] = v.x; op[CI_S] = v.y; op[2 * CI_S] = v.z; op[3 * CI_S] = v.w;
             }
         }
+        PHASE_STAMP(8);
         PHASE_STAMP(9);
         PHASE_FLUSH;
         return;

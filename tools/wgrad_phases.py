@@ -13,7 +13,7 @@ from __graft_entry__ import load_package  # noqa: E402
 
 NAMES = ["first barrier (waiting for the other waves' MFMAs)", "waiting for this tile's global loads", "LDS writes (transposing store)",
          "second barrier", "issuing the next tile's loads", "operand reads + transforms + MFMAs", "the tail's first barrier (skew of the waves at the end of the loop)",
-         "four cross-wave reduction passes through LDS", "row transform Z = dU G through LDS", "column transform + slab store"]
+         "the wave's own back-transform, its 9 taps to LDS, barrier", "sum over the row-group waves + slab store", "(unused)"]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=16)
