@@ -29,6 +29,22 @@ namespace {
 #define NGAN_TILE_DOUBLE_BUFFER 0      // measured, round 3: slower (below)
 #endif
 
+// Phase-timer build only (`make phases`; tools/wgrad_phases.py --op fwd): shader-clock stamps, summed over the sampled waves (one workgroup in
+// eight).  0 = the tile's first barrier, 1 = waiting for the tile's loads + LDS writes, 2 = second barrier, 3 = issuing the next tile's loads +
+// the epilogue's scalars / operand requests, 4 = transforms + MFMAs, 5 = epilogue arithmetic + stores, 6 = number of waves
+#ifdef NGAN_DIAG_PHASES
+__device__ unsigned long long tile_phase_ctr[11];      // 7 = earliest loop entry, 8 = latest exit, 9 = sum of entries, 10 = sum of exits (s_memrealtime, 100 MHz)
+#define TPH_INIT unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter(), t0_ = __builtin_amdgcn_s_memrealtime()
+#define TPH(i) { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] += now_ - last_; last_ = now_; }
+#define TPH_FLUSH if (lane == 0 && (blockIdx.x & 7) == 0) { const unsigned long long t1_ = __builtin_amdgcn_s_memrealtime(); \
+    for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&tile_phase_ctr[i_], ph_[i_]); atomicAdd(&tile_phase_ctr[6], 1ull); \
+    atomicMin(&tile_phase_ctr[7], t0_); atomicMax(&tile_phase_ctr[8], t1_); atomicAdd(&tile_phase_ctr[9], t0_); atomicAdd(&tile_phase_ctr[10], t1_); }
+#else
+#define TPH_INIT
+#define TPH(i)
+#define TPH_FLUSH
+#endif
+
 template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
 __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) ? (PREC ? 3 : 4) : 2) void conv3x3_tile_kernel(ConvArgs a, int n_tiles) {
     // PREC: 0 exact fp32 (direct), 1 split bf16, 2 exact fp32 by Winograd F(2x2, 3x3) (16 -> 16 only; see the MFMA section),
@@ -186,6 +202,7 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
     }
     float* const tile0 = tile;
     int cur = 0;
+    TPH_INIT;
     while (t < t_end) {
         const int b = cur_tile.b, y0 = cur_tile.ty * THc, x0 = cur_tile.tx * 32;
         const int tn = t + run.step;
@@ -196,8 +213,11 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
             if (tn + run.step < t_end) issue(walk.next(next_tile));
         } else {
             __syncthreads();   // previous tile's MFMAs have finished reading `tile`
+            TPH(0);
             stage(tile);
+            TPH(1);
             __syncthreads();
+            TPH(2);
             if (tn < t_end) issue(next_tile);   // in flight while this tile is computed
         }
 
@@ -238,6 +258,7 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
         };
         if (PRE) load_pn_operands();
 
+        TPH(3);
         f32x4 acc[PGW][MTW];
 #pragma unroll
         for (int pg = 0; pg < PGW; ++pg)
@@ -369,6 +390,7 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
                 }
             }
         }
+        TPH(4);
         // ---- epilogue ----
         if (PNB && !PRE) load_pn_operands();
         // PixelNorm-backward operands: wait for everything in flight (the operand loads and the next tile, issued a tile's worth of
@@ -530,10 +552,12 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
             __syncthreads();   // every wave has finished reading this tile's buffer and writing the next tile's
             cur ^= 1;
         }
+        TPH(5);
         t = tn;
         cur_tile = next_tile;
         next_tile = walk.next(next_tile);
     }
+    TPH_FLUSH;
 }
 
 template <int MTW, int KG, int EPI, int OUTMODE, int PREC>
@@ -601,5 +625,18 @@ extern "C" int ngan_diag_conv3x3_bf16x6(const float* x, const float* w, const fl
     hipLaunchKernelGGL(pack_weights_bf16x6_kernel, dim3(30), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(packed), scale);
     ConvArgs a{x, packed, bias, y, rnorm, B, H, W, 16, 16, 0, 0, slope, eps, nullptr, nullptr, nullptr};
     return epilogue ? launch_tile<1, 1, 1, 0, 3>(a, s) : launch_tile<1, 1, 0, 0, 3>(a, s);
+}
+#endif
+
+#ifdef NGAN_DIAG_PHASES
+// phase-timer build only (not declared in include/ngan.h): copies the phase counters of conv3x3_tile_kernel out and optionally zeroes them
+extern "C" int ngan_diag_tile_phases(unsigned long long* out11, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out11, HIP_SYMBOL(tile_phase_ctr), 11 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long z[11] = {0, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tile_phase_ctr), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
 }
 #endif

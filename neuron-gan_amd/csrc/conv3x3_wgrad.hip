@@ -56,11 +56,13 @@ constexpr int pad_plane(int n) { return n + ((4 - n % 64) + 64) % 64; }
 // waves + slab store (and the further output groups' rounds), 9 = unused, 10 = number of waves sampled (one workgroup in eight reports: with
 // every wave reporting, the atomics of the early finishers stood in the way of the others' tails and tripled the tail's apparent cost).
 #ifdef NGAN_DIAG_PHASES
-__device__ unsigned long long wgrad_phase_ctr[11];
-#define PHASE_INIT unsigned long long ph_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter()
+__device__ unsigned long long wgrad_phase_ctr[15];      // 11 = earliest loop entry, 12 = latest exit, 13 / 14 = sums of entries / exits (s_memrealtime, 100 MHz)
+#define PHASE_INIT unsigned long long ph_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter(), t0_ = __builtin_amdgcn_s_memrealtime()
 #define PHASE_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); ph_[i] += now_ - last_; last_ = now_; }
 #define PHASE_WAIT_LOADS asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define PHASE_FLUSH if (lane == 0 && (blockIdx.x & 7) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&wgrad_phase_ctr[i_], ph_[i_]); atomicAdd(&wgrad_phase_ctr[10], 1ull); }
+#define PHASE_FLUSH if (lane == 0 && (blockIdx.x & 7) == 0) { const unsigned long long t1_ = __builtin_amdgcn_s_memrealtime(); \
+    for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&wgrad_phase_ctr[i_], ph_[i_]); atomicAdd(&wgrad_phase_ctr[10], 1ull); \
+    atomicMin(&wgrad_phase_ctr[11], t0_); atomicMax(&wgrad_phase_ctr[12], t1_); atomicAdd(&wgrad_phase_ctr[13], t0_); atomicAdd(&wgrad_phase_ctr[14], t1_); }
 #else
 #define PHASE_INIT
 #define PHASE_STAMP(i)
@@ -1080,9 +1082,9 @@ extern "C" int ngan_bf16_conv3x3_wgrad(const ngan_bf16* x, const ngan_bf16* g, f
 // phase-timer build only (not declared in include/ngan.h): copies the phase counters of wgrad_f32_kernel out and optionally zeroes them
 extern "C" int ngan_diag_wgrad_phases(unsigned long long* out11, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(out11, HIP_SYMBOL(wgrad_phase_ctr), 11 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out11, HIP_SYMBOL(wgrad_phase_ctr), 15 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
-        const unsigned long long z[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long z[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(wgrad_phase_ctr), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;

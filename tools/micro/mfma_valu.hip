@@ -11,6 +11,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int KIND, int N>
 __global__ __launch_bounds__(64) void k(float* out, int iters) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();      // shader clock / 100 MHz reference
     f32x4 acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float a = threadIdx.x * 0.001f + 1.0f, b = 0.5f + blockIdx.x * 1e-6f;
@@ -36,6 +37,11 @@ __global__ __launch_bounds__(64) void k(float* out, int iters) {
     for (int i = 0; i < 8; ++i) s += r[i][0] + r[i][1];
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 123.456f) out[threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // the clock this wave ran at: shader cycles per 10 ns of the constant reference counter
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        out[512] = (float)(c1 - c0);
+        out[513] = (float)(r1 - r0);
+    }
 }
 
 template <int KIND, int N>
@@ -52,8 +58,11 @@ void run(float* out, int wps) {
     const double us = ms * 1e3 / 5;
     const double mfma_per_simd = 16.0 * iters * wps;
     static const char* names[] = {"none", "v_fma_f32", "v_pk_fma_f32", "v_add_f32", "v_pk_add_f32", "s_nop 0"};
-    printf("%-14s N=%d  waves/SIMD %d  %9.1f us  %6.1f cycles per MFMA slot at 2.4 GHz  (%5.1f TFLOP/s of MFMA)\n", names[KIND], N, wps, us,
-           us * 2400.0 / mfma_per_simd, 2048.0 * 16 * iters * grid / us / 1e6);
+    float clk[2];
+    hipMemcpy(clk, out + 512, sizeof(clk), hipMemcpyDeviceToHost);
+    const double ghz = clk[1] > 0 ? clk[0] / (clk[1] * 10.0) : 0.0;       // shader cycles per ns
+    printf("%-14s N=%d  waves/SIMD %d  %9.1f us  %6.1f cycles per MFMA slot at 2.4 GHz  (%5.1f TFLOP/s of MFMA)  in-kernel clock %.2f GHz (s_memtime / s_memrealtime) -> %5.1f of ITS cycles per slot\n",
+           names[KIND], N, wps, us, us * 2400.0 / mfma_per_simd, 2048.0 * 16 * iters * grid / us / 1e6, ghz, us * 1e3 * ghz / mfma_per_simd);
 }
 
 template <int KIND>
@@ -65,7 +74,7 @@ void sweep(float* out) {
 }
 
 int main() {
-    float* out; hipMalloc(&out, 4096);
+    float* out; hipMalloc(&out, 4096);      // (floats 512, 513: the clock probe)
     sweep<0>(out); sweep<1>(out); sweep<2>(out); sweep<3>(out); sweep<4>(out); sweep<5>(out);
     return 0;
 }
