@@ -33,6 +33,11 @@ e1.record()
 torch.cuda.synchronize()
 assert lib.ngan_diag_wgrad_phases(w, 1) == 0 and lib.ngan_diag_tile_phases(t, 1) == 0
 print(f"50 replayed iterations, {e0.elapsed_time(e1) / 50:.3f} ms each (phase-timer build)")
-for name, c, nph, cn, o in (("wgrad_f32_kernel (all Winograd weight-gradient launches)", w, 10, 10, 11), ("conv3x3_tile_kernel (all 16 -> 16 forward / input-gradient launches)", t, 6, 6, 7)):
+WG = ["first barrier", "waiting for the tile's loads", "LDS writes (transposing store)", "second barrier", "issuing the next tile's loads", "operand reads + transforms + MFMAs",
+      "the tail's first barrier", "own back-transform + 9 taps to LDS + barrier", "sum over the row-group waves + slab store", "(unused)"]
+TL = ["first barrier", "waiting for the tile's loads + LDS writes", "second barrier", "issuing the next tile's loads + epilogue scalars", "transforms + MFMAs", "epilogue arithmetic + stores (incl. the MFMA drain)"]
+for name, c, names, cn, o in (("wgrad_f32_kernel (all Winograd weight-gradient launches)", w, WG, 10, 11), ("conv3x3_tile_kernel (all 16 -> 16 forward / input-gradient launches)", t, TL, 6, 7)):
+    nph = len(names)
     cyc, life = sum(c[:nph]), (c[o + 3] - c[o + 2]) / 100.0     # shader cycles; microseconds
     print(f"  {name}: {c[cn]} sampled waves, {cyc / c[cn]:.0f} shader cycles and {life / c[cn]:.1f} us per wave on average: {cyc / life / 1e3:.2f} GHz")
+    print("      " + "; ".join(f"{n} {c[i] / cyc * 100:.1f} %" for i, n in enumerate(names) if c[i] / cyc > 0.001))
