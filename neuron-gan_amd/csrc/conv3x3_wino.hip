@@ -71,7 +71,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
     const int p = lane & 15, q = lane >> 4;
     const int cb = nh * MTW * 16;                                 // first output channel of this wave
 
-    for (int e = tid; e < W_ELEMS / 4; e += NT) st4(wl + e * 4, ld4(a.wp + e * 4));
 #if NGAN_WINO_PRIO
     if (NWAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);      // experiment: static priority for the later-dispatched half
 #endif
@@ -185,6 +184,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_wino_kernel(ConvArgs a
         wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + cb + mt * 16 + q * 4) : f4zero();
     }
     if (t < t_end) issue(cur_tile);
+    {   // the packed weights -> LDS, requested BEHIND the first tile's loads and all at once: one memory round trip for both (the copy used to run
+        // first, in its own one or two round trips, before the first tile was even requested: ~2 us of every launch)
+        constexpr int NWL = (W_ELEMS / 4 + NT - 1) / NT;
+        float4 wtmp[NWL];
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) wtmp[i] = (tid + i * NT < W_ELEMS / 4) ? ld4(a.wp + (long)(tid + i * NT) * 4) : f4zero();
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+            if (tid + i * NT < W_ELEMS / 4) st4(wl + (tid + i * NT) * 4, wtmp[i]);
+    }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) { pin_registers(bvec[mt]); pin_registers(wimg[mt]); }     // (awaited once, here: conv3x3_internal.h)
     const float inv_n = 1.0f / (float)N;
