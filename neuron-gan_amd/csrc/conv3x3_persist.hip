@@ -45,7 +45,6 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
     const int p = lane & 15, q = lane >> 4;
     constexpr int K = KG * 16, N = MTW * 16;
 
-    for (int e = tid; e < W_ELEMS / 4; e += 256) st4(wl + e * 4, ld4(a.wp + e * 4));
 
     const TileRun run = tile_run(n_tiles);
     int t = run.t;
@@ -170,6 +169,15 @@ __global__ __launch_bounds__(256, PREC == 2 ? NGAN_WINO16_WPE : (MTW * KG == 1) 
         wimg[mt] = EPI == EPI_TO_IMAGE ? ld4(a.ay + mt * 16 + q * 4) : f4zero();
     }
     if (t < t_end) issue(t);
+    {   // the packed weights -> LDS, requested behind the first tile's loads and all at once (conv3x3_tile_kernel)
+        constexpr int NWL = (W_ELEMS / 4 + 255) / 256;
+        float4 wtmp[NWL];
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) wtmp[i] = (tid + i * 256 < W_ELEMS / 4) ? ld4(a.wp + (long)(tid + i * 256) * 4) : f4zero();
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+            if (tid + i * 256 < W_ELEMS / 4) st4(wl + (tid + i * 256) * 4, wtmp[i]);
+    }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) { pin_registers(bv[mt]); pin_registers(wimg[mt]); }     // (awaited once, here: conv3x3_internal.h)
     const float inv_n = 1.0f / (float)N;
