@@ -83,6 +83,8 @@ __device__ unsigned long long wgrad_phase_ctr[15];      // 11 = earliest loop en
 //    packed fp32 instructions in an MFMA's shadow again, and rightly -- beside v_mfma_f32_16x16x4_f32 at two waves per SIMD a packed
 //    instruction costs 5 - 9 cycles of the slot against 3 - 5 for a scalar one (tools/micro/mfma_valu.hip);
 //  * 768 / 1024 instead of 512 workgroups (three per CU): 42.1 -> 43.0 / 46.7 us.
+//  * pairs of adjacent pixels per thread so that the transposing store of g is one ds_write_b64 per channel instead of two ds_write_b32
+//    (8 instead of 16 LDS instructions per thread and tile; conflict-free): 707 -> 713 us per iteration for the dominant instance: nothing.
 template <int COT, int CIT, int RES, int TW, int NW, int XF, int WINO = 0>
 __global__ __launch_bounds__(NW * 64, (WINO && !XF && COT * CIT == 1) ? 2 : (COT * CIT == 1) ? 3 : (COT * CIT == 2 || NW == 4 ? 2 : 1)) void wgrad_f32_kernel(WgradArgs a) {
     // Winograd form: a wave step covers 16 Winograd tiles -- one row of an 8 x 32 tile, or (TW = 16: images at most 16 pixels wide)
